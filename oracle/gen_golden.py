@@ -1,0 +1,244 @@
+"""Generate the committed golden fixtures under tests/golden/ by RUNNING THE REFERENCE'S OWN CODE.
+
+Run in the build container only (needs /root/reference):   python oracle/gen_golden.py
+TEST INFRASTRUCTURE ONLY.
+
+What is executed from the reference (unmodified):
+  * models/embedder.py, models/fields.py, models/renderer.py  -- imported as modules (oracle/ref_loader.py)
+  * models/dataset.py: SMPL_Dataset.gen_rays_pose / near_far_from_sphere and models/utils.py: lookat,
+    sphere_coord, random_eye_normal, random_at -- their function bodies are extracted with `ast` and compiled
+    stand-alone, because the modules' import blocks need cv2 / imageio / neural_renderer (absent here).
+Fixtures:
+  neus_small.npz   shipped small checkpoint (real weights), camera 58 of zero_beta_standpose_render,
+                   256 rays, perturb 0: per-step up-sampling intermediates, render outputs, parameter grads
+  neus_full.npz    full-size nets (confs/examples/*.conf), torch.manual_seed(0) geometric init + perturbed
+                   weights, 96 rays, injected jitter
+  sampling_kat.npz known-answer vectors for sample_pdf / up_sample on seeded inputs
+  rays_cam.npz     ray generation / near-far / camera helpers
+"""
+import ast
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+warnings.filterwarnings("ignore")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import ref_loader  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def extract_functions(path, names, class_name=None):
+    """Compile selected function defs of a reference source file stand-alone (no module imports run)."""
+    src = open(path).read()
+    tree = ast.parse(src)
+    body = tree.body
+    if class_name is not None:
+        body = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == class_name][0].body
+    fns = [n for n in body if isinstance(n, ast.FunctionDef) and n.name in names]
+    mod = ast.Module(body=fns, type_ignores=[])
+    ns = {"torch": torch, "np": np}
+    exec(compile(mod, path, "exec"), ns)
+    return {n: ns[n] for n in names}
+
+
+def sd_np(sd, prefix):
+    return {prefix + k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def ref_upsample_trace(R, ren, rays_o, rays_d, near, far, jitter):
+    """The no_grad block of NeuSRenderer.render (renderer.py:304-352) driven step by step through the
+    reference's own up_sample / cat_z_vals so the intermediates can be recorded."""
+    n_samples = ren.n_samples
+    z_vals = torch.linspace(0.0, 1.0, n_samples)
+    z_vals = near + (far - near) * z_vals[None, :]
+    if jitter is not None:
+        z_vals = z_vals + (jitter - 0.5) * 2.0 / n_samples
+    steps = []
+    with torch.no_grad():
+        pts = rays_o[:, None, :] + rays_d[:, None, :] * z_vals[..., :, None]
+        sdf = ren.sdf_network.sdf(pts.reshape(-1, 3)).reshape(len(rays_o), n_samples)
+        for i in range(ren.up_sample_steps):
+            new_z = ren.up_sample(rays_o, rays_d, z_vals, sdf, ren.n_importance // ren.up_sample_steps, 64 * 2 ** i)
+            steps.append((z_vals.clone(), sdf.clone(), new_z.clone()))
+            z_vals, sdf = ren.cat_z_vals(rays_o, rays_d, z_vals, new_z, sdf, last=(i + 1 == ren.up_sample_steps))
+    return z_vals, steps
+
+
+def scalar_loss(out, coef):
+    """A fixed scalar functional of the render outputs that exercises every gradient path used by
+    main.py:426-534 (colour, CLIP colour, weight_sum/BCE, eikonal, shading normals)."""
+    normals = (out["gradients"] * out["weights"][:, :, None]).sum(dim=1)
+    normals = normals / (torch.norm(normals, dim=-1, keepdim=True) + 1e-7)
+    loss = (out["color_fine"] * coef["c1"]).sum() + (out["extra_color_fine"] * coef["c2"]).sum()
+    loss = loss + 0.1 * out["gradient_error"] * coef["c1"].shape[0]
+    loss = loss + torch.nn.functional.binary_cross_entropy(out["weight_sum"].clip(1e-3, 1 - 1e-3), coef["mask"],
+                                                           reduction="sum")
+    loss = loss + (normals * coef["c3"]).sum()
+    return loss
+
+
+def run_case(R, sdf_net, col_net, var_net, n_samples, n_importance, steps, rays_o, rays_d, near, far, jitter,
+             bg, cos_anneal, seed):
+    ren = R.NeuSRenderer(None, sdf_net, var_net, col_net, n_samples=n_samples, n_importance=n_importance,
+                         n_outside=0, up_sample_steps=steps, perturb=1.0 if jitter is not None else 0.0,
+                         extra_color=True)
+    z_final, trace = ref_upsample_trace(R, ren, rays_o, rays_d, near, far, jitter)
+    # full reference render() with the same jitter injected through torch.rand
+    orig_rand = torch.rand
+    if jitter is not None:
+        torch.rand = lambda *a, **k: jitter.clone()
+    try:
+        out = ren.render(rays_o, rays_d, near, far, perturb_overwrite=-1 if jitter is not None else 0,
+                         background_rgb=bg, cos_anneal_ratio=cos_anneal)
+    finally:
+        torch.rand = orig_rand
+    # the traced z must reproduce render()'s own z (mid_z_vals = z + dists/2)
+    g = torch.Generator().manual_seed(seed)
+    Rn = rays_o.shape[0]
+    coef = dict(c1=torch.randn(Rn, 3, generator=g) * 0.1, c2=torch.randn(Rn, 3, generator=g) * 0.1,
+                c3=torch.randn(Rn, 3, generator=g) * 0.1, mask=(torch.rand(Rn, 1, generator=g) > 0.5).float())
+    loss = scalar_loss(out, coef)
+    params = [p for net in (sdf_net, var_net, col_net) for p in net.parameters()]
+    names = [pfx + n for pfx, net in (("sdf.", sdf_net), ("var.", var_net), ("col.", col_net))
+             for n, _ in net.named_parameters()]
+    grads = torch.autograd.grad(loss, params, allow_unused=True)
+    rec = {}
+    rec.update(rays_o=rays_o, rays_d=rays_d, near=near, far=far)
+    if jitter is not None:
+        rec["jitter"] = jitter
+    rec["bg"] = bg if bg is not None else torch.zeros(0)
+    rec["cos_anneal"] = torch.tensor(cos_anneal)
+    rec["z_final"] = z_final
+    for i, (zi, si, nz) in enumerate(trace):
+        rec["up%d_z_in" % i] = zi
+        rec["up%d_sdf_in" % i] = si
+        rec["up%d_new_z" % i] = nz
+    for k in ("color_fine", "extra_color_fine", "weight_sum", "weight_max", "gradients", "weights",
+              "mid_z_vals", "gradient_error", "inside_sphere", "cdf_fine", "s_val"):
+        rec["out_" + k] = out[k]
+    for k, v in coef.items():
+        rec["coef_" + k] = v
+    rec["loss"] = loss
+    for n, gr, p in zip(names, grads, params):
+        rec["grad_" + n] = gr if gr is not None else torch.zeros_like(p)
+    rec = {k: v.detach().cpu().numpy().astype(np.float32) for k, v in rec.items()}
+    # effective (weight-normed) dense weights, so consumers can bypass g/v handling
+    return rec
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    R = ref_loader.load_reference()
+    AG = R.ref_ag
+    ds_fns = extract_functions(os.path.join(AG, "models", "dataset.py"),
+                               ["gen_rays_pose", "near_far_from_sphere"], "SMPL_Dataset")
+    ut_fns = extract_functions(os.path.join(AG, "models", "utils.py"),
+                               ["norm_np_arr", "lookat", "sphere_coord", "random_eye_normal", "random_at", "random_eye"])
+    # make extracted helpers see each other
+    for f in ut_fns.values():
+        f.__globals__.update(ut_fns)
+
+    meta = json.load(open(os.path.join(AG, "data", "zero_beta_standpose_render", "transforms_train.json")))
+    H = W = 256
+    focal = 0.5 * W / np.tan(0.5 * float(meta["camera_angle_x"]))  # dataset.py:234-235
+    K = torch.from_numpy(np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]]))  # dataset.py:243-247
+    fake_self = type("DS", (), {})()
+    fake_self.W, fake_self.H, fake_self.K = W, H, K
+
+    # ---------------- rays / cameras
+    pose58 = torch.tensor(meta["frames"][58]["transform_matrix"]).float()
+    rec = {}
+    for lvl in (4, 2.25):
+        o, v = ds_fns["gen_rays_pose"](fake_self, pose58, lvl)
+        rec["rays_o_l%s" % lvl] = o.contiguous().numpy()
+        rec["rays_v_l%s" % lvl] = v.numpy()
+    o4, v4 = ds_fns["gen_rays_pose"](fake_self, pose58, 4)
+    near, far = ds_fns["near_far_from_sphere"](fake_self, o4.reshape(-1, 3), v4.reshape(-1, 3))
+    rec.update(pose58=pose58.numpy(), focal=np.float64(focal), near_l4=near.numpy(), far_l4=far.numpy())
+    np.random.seed(0)
+    eyes, ats, poses, aux = [], [], [], []
+    for _ in range(8):
+        eye, theta, phi, is_front = ut_fns["random_eye_normal"]()
+        at = ut_fns["random_at"]().astype(np.float32)
+        eye = eye.astype(np.float32) + at
+        poses.append(ut_fns["lookat"](eye, at, np.array([0, 1, 0])))
+        eyes.append(eye); ats.append(at); aux.append([theta, phi, is_front])
+    rec.update(cam_eye=np.array(eyes), cam_at=np.array(ats), cam_pose=np.array(poses), cam_aux=np.array(aux),
+               sphere_coord=np.array([ut_fns["sphere_coord"](0.3 * i, 0.7 * i) for i in range(6)]))
+    np.savez_compressed(os.path.join(GOLD, "rays_cam.npz"), **rec)
+
+    # ---------------- small net, real checkpoint
+    torch.manual_seed(0)
+    ck = torch.load(R.small_ckpt, map_location="cpu", weights_only=False)
+    sdf = R.SDFNetwork(**ref_loader.SMALL_SDF)
+    sdf.load_state_dict(ck["sdf_network_fine"])
+    col = R.RenderingNetwork(**ref_loader.SMALL_COLOR)
+    col.load_state_dict(ck["color_network_fine"], strict=False)  # main.py:617 (extra_lin keeps its random init)
+    var = R.SingleVarianceNetwork(0.3)
+    var.load_state_dict(ck["variance_network_fine"])
+    ro, rd = o4.reshape(-1, 3).float().contiguous(), v4.reshape(-1, 3).float().contiguous()
+    ren = R.NeuSRenderer(None, sdf, var, col, 32, 32, 0, 4, 0.0, True)
+    ws = ren.render(ro, rd, near, far, perturb_overwrite=0)["weight_sum"].detach().reshape(-1)
+    hit = torch.nonzero(ws > 0.5).reshape(-1)
+    edge = torch.nonzero((ws > 0.02) & (ws <= 0.5)).reshape(-1)
+    miss = torch.nonzero(ws <= 0.02).reshape(-1)
+    g = torch.Generator().manual_seed(1)
+    sel = torch.cat([hit[torch.randperm(len(hit), generator=g)[:160]], edge[:32],
+                     miss[torch.randperm(len(miss), generator=g)[:64]]])
+    sel = sel[:256]
+    print("small: hit %d edge %d miss %d -> %d rays" % (len(hit), len(edge), len(miss), len(sel)))
+    rec = run_case(R, sdf, col, var, 32, 32, 4, ro[sel], rd[sel], near[sel], far[sel], None,
+                   torch.tensor([[0.2, 0.5, 0.9]]), 1.0, seed=2)
+    rec["ray_index"] = sel.numpy()
+    rec.update(sd_np(sdf.state_dict(), "sdf."))
+    rec.update(sd_np(col.state_dict(), "col."))
+    rec.update(sd_np(var.state_dict(), "var."))
+    np.savez_compressed(os.path.join(GOLD, "neus_small.npz"), **rec)
+
+    # ---------------- full-size nets, seeded
+    torch.manual_seed(0)
+    sdf = R.SDFNetwork(**ref_loader.FULL_SDF)
+    col = R.RenderingNetwork(**ref_loader.FULL_COLOR)
+    var = R.SingleVarianceNetwork(0.3)
+    with torch.no_grad():  # move off the degenerate init so every weight matters (PE columns are 0 at init)
+        for p in list(sdf.parameters()) + list(col.parameters()):
+            p.add_(torch.randn_like(p) * 0.02 * p.abs().mean().clamp(min=0.05))
+        var.variance.fill_(0.45)
+    eye = np.array([0.6, 0.4, 1.3], dtype=np.float32)
+    pose = torch.from_numpy(ut_fns["lookat"](eye, np.zeros(3, np.float32), np.array([0, 1, 0]))).float()
+    fake_self.W = fake_self.H = 24
+    f24 = 0.5 * 24 / np.tan(np.pi / 6)
+    fake_self.K = torch.from_numpy(np.array([[f24, 0, 12.0], [0, f24, 12.0], [0, 0, 1]]))
+    o, v = ds_fns["gen_rays_pose"](fake_self, pose, 2)
+    ro, rd = o.reshape(-1, 3).float().contiguous(), v.reshape(-1, 3).float().contiguous()
+    nearf, farf = ds_fns["near_far_from_sphere"](fake_self, ro, rd)
+    ro, rd, nearf, farf = ro[:96], rd[:96], nearf[:96], farf[:96]
+    jitter = torch.rand(96, 1, generator=torch.Generator().manual_seed(3))
+    rec = run_case(R, sdf, col, var, 32, 32, 4, ro, rd, nearf, farf, jitter, None, 0.3, seed=4)
+    rec.update(sd_np(sdf.state_dict(), "sdf."))
+    rec.update(sd_np(col.state_dict(), "col."))
+    rec.update(sd_np(var.state_dict(), "var."))
+    np.savez_compressed(os.path.join(GOLD, "neus_full.npz"), **rec)
+
+    # ---------------- sampling KATs
+    g = torch.Generator().manual_seed(5)
+    bins = torch.sort(torch.rand(16, 24, generator=g) * 2 + 0.5, dim=-1)[0]
+    wts = torch.rand(16, 23, generator=g) ** 4
+    wts[3] = 0  # degenerate pdf row
+    wts[5, :20] = 0
+    sp = R.sample_pdf(bins, wts, 8, det=True)
+    np.savez_compressed(os.path.join(GOLD, "sampling_kat.npz"), bins=bins.numpy(), weights=wts.numpy(),
+                        samples=sp.numpy())
+    for f in sorted(os.listdir(GOLD)):
+        print(f, os.path.getsize(os.path.join(GOLD, f)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,179 @@
+// Common device helpers for the AvatarCLIP/NeuS gfx950 kernels.
+//
+// MLP engine: one wavefront owns 32 sample points and keeps every activation in registers.
+// All layer products are computed TRANSPOSED (H^T = W * X^T) with v_mfma_f32_32x32x16_{f16,bf16}:
+//     A operand = packed weights   (lane l: row 32t+(l&31), 8 k-slots of half h=l>>5)
+//     B operand = activations      (lane l: point p=l&31,  8 k-slots of half h=l>>5)
+//     C/D       = 32 features x 32 points, lane l holds point p=l&31 and the 16 feature rows
+//                 row(r,h) = (r&3) + 8*(r>>2) + 4*h                      (MI355X C/D layout)
+// so the accumulator of out-tile t becomes, after the activation and a cvt to 16 bit, exactly the B operand
+// of k-steps 2t (regs 0..7) and 2t+1 (regs 8..15) of the next layer -- no LDS, no cross-lane traffic.
+// The k-slot <-> feature permutation this induces,
+//     feature(s,h,j) = 32*(s>>1) + 16*(s&1) + 8*(j>>2) + 4*h + (j&3),
+// is baked into the host-side weight packing (avatarclip_amd/packing.py).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef float facc __attribute__((ext_vector_type(16)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+#define AVC_BETA 100.0f
+#define AVC_INV_BETA 0.01f
+
+// ---- offsets of the packed parameter blobs (element units of the blob's dtype); mirrored by packing.py,
+// ---- which parses this enum.  *_T = transposed weight (rows = in-features).
+enum AvcOff {
+  // 16-bit packs (same slot numbering for the f16 and the bf16 blob)
+  OFF_W0 = 0, OFF_WM0, OFF_WM1, OFF_WS, OFF_WL,          // SDF forward: layer0, middle0, middle1, skip, last(rows 1..H)
+  OFF_W0T, OFF_WM0T, OFF_WM1T, OFF_WST, OFF_WLT,         // SDF transposed (WLT: rows = [skip feats | pe slots], K = H feature rows 1..H)
+  OFF_C0, OFF_CM0, OFF_CH,                               // colour forward: layer0 (K = feat + [x,n]), middle, heads(6 rows)
+  OFF_C0T, OFF_CM0T, OFF_CHT,                            // colour transposed
+  // fp32 tables
+  OFF_B0, OFF_BM0, OFF_BM1, OFF_BS, OFF_BL, OFF_BL0,     // packed biases (acc order), BL0 = scalar sdf bias
+  OFF_WL0_ACC, OFF_WL0_FRAG, OFF_WL0_PE,                 // row 0 of the last layer / sqrt2 in acc order, frag order, pe-slot order
+  OFF_CB0, OFF_CBM0, OFF_CBH,
+  OFF_COUNT
+};
+struct AvcOffsets { int v[OFF_COUNT]; };
+
+// ---------------------------------------------------------------------------------------------
+template <typename V> struct MF;
+template <> struct MF<h8> {
+  typedef _Float16 S;
+  static __device__ __forceinline__ facc mma(h8 a, h8 b, facc c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct MF<b8> {
+  typedef __bf16 S;
+  static __device__ __forceinline__ facc mma(b8 a, b8 b, facc c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+// One 32-feature output tile: acc = sum_s Wp[s] * in[s].  wp points at this lane's 16-B chunk of k-step 0
+// of the tile; consecutive k-steps are 64 chunks apart.
+template <typename V, int KS>
+__device__ __forceinline__ facc tile_gemm(const V* __restrict__ wp, const V (&in)[KS]) {
+  facc acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) acc = MF<V>::mma(wp[s * 64], in[s], acc);
+  __builtin_amdgcn_sched_barrier(0);
+  return acc;
+}
+// same, but the K dimension is split over two register arrays (skip connection / concatenated inputs)
+template <typename V, int KA, int KB>
+__device__ __forceinline__ facc tile_gemm2(const V* __restrict__ wp, const V (&ina)[KA], const V (&inb)[KB]) {
+  facc acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < KA; ++s) acc = MF<V>::mma(wp[s * 64], ina[s], acc);
+#pragma unroll
+  for (int s = 0; s < KB; ++s) acc = MF<V>::mma(wp[(KA + s) * 64], inb[s], acc);
+  __builtin_amdgcn_sched_barrier(0);
+  return acc;
+}
+
+// packed per-tile fp32 table [tile][half][16] -> this lane's 16 values
+__device__ __forceinline__ void load16(const float* __restrict__ tab, int t, int h, float (&out)[16]) {
+  const f4* p = reinterpret_cast<const f4*>(tab + (t * 2 + h) * 16);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f4 v = p[q];
+    out[4 * q + 0] = v[0]; out[4 * q + 1] = v[1]; out[4 * q + 2] = v[2]; out[4 * q + 3] = v[3];
+  }
+}
+// frag-order fp32 table [kstep][half][8] -> this lane's 8 values
+__device__ __forceinline__ void load8(const float* __restrict__ tab, int s, int h, float (&out)[8]) {
+  const f4* p = reinterpret_cast<const f4*>(tab + (s * 2 + h) * 8);
+  f4 a = p[0], b = p[1];
+  out[0] = a[0]; out[1] = a[1]; out[2] = a[2]; out[3] = a[3];
+  out[4] = b[0]; out[5] = b[1]; out[6] = b[2]; out[7] = b[3];
+}
+
+__device__ __forceinline__ float softplus100(float a) {
+  // nn.Softplus(beta=100): log(1+exp(100 a))/100 (fields.py:68); stable form
+  float e = __expf(-fabsf(a) * AVC_BETA);
+  return fmaxf(a, 0.f) + __logf(1.f + e) * AVC_INV_BETA;
+}
+// sigma(beta a) recovered from h = softplus(a):  1 - exp(-beta h)
+__device__ __forceinline__ float sig_from_h(float h) { return 1.f - __expf(-AVC_BETA * h); }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+template <typename V> __device__ __forceinline__ void set8(V& f, int j, float v) { f[j] = (typename MF<V>::S)v; }
+template <typename V> __device__ __forceinline__ float get8(const V& f, int j) { return (float)f[j]; }
+
+// accumulator tile (already activated, fp32) -> the two B-operand k-steps it feeds
+template <typename V>
+__device__ __forceinline__ void acc_to_frags(const float (&a)[16], V& f0, V& f1) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { set8(f0, j, a[j]); set8(f1, j, a[8 + j]); }
+}
+
+__device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32); }
+
+// Positional-encoding slots (host mirror: packing.pe_slot_table):
+//   half 0: q 0..2 = x_c ; q 3+6k+c = sin(2^k x_c), 6+6k+c = cos(2^k x_c) for k=0..2 ; q 21..23 = x_lo_c
+//   half 1: q 6k'+c = sin(2^(3+k') x_c), 6k'+3+c = cos(...)  for k'=0..2 ; q 18..23 = 0
+// vals[q] = fp32 value, dcoef[q] = d vals[q] / d x_c (c = slot's coordinate), coord implicit (c = (q % 3) pattern).
+struct PE {
+  float v[24];   // feature value
+  float d[24];   // derivative of the feature wrt its coordinate
+};
+__device__ __forceinline__ void pe_compute(const float (&x)[3], int h, PE& pe) {
+  // static register indexing only (a lane-dependent index would send the arrays to scratch)
+  const float f0 = h ? 8.f : 1.f;
+  float sn[3][3], cs[3][3], fr[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    fr[k] = f0 * (float)(1 << k);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) __sincosf(x[c] * fr[k], &sn[k][c], &cs[k][c]);
+  }
+#pragma unroll
+  for (int q = 0; q < 24; ++q) {
+    // half-0 view of slot q
+    float v0 = 0.f, d0 = 0.f;
+    if (q < 3) { v0 = x[q]; d0 = 1.f; }
+    else if (q < 21) {
+      const int k = (q - 3) / 6, rem = (q - 3) % 6;
+      if (rem < 3) { v0 = sn[k][rem]; d0 = fr[k] * cs[k][rem]; }
+      else { v0 = cs[k][rem - 3]; d0 = -fr[k] * sn[k][rem - 3]; }
+    }
+    // half-1 view
+    float v1 = 0.f, d1 = 0.f;
+    if (q < 18) {
+      const int k = q / 6, rem = q % 6;
+      if (rem < 3) { v1 = sn[k][rem]; d1 = fr[k] * cs[k][rem]; }
+      else { v1 = cs[k][rem - 3]; d1 = -fr[k] * sn[k][rem - 3]; }
+    }
+    pe.v[q] = h ? v1 : v0;
+    pe.d[q] = h ? d1 : d0;
+  }
+}
+// PE values -> three f16 k-steps (with the hi/lo split of x: slot c holds fp16(x), slot 21+c the residual)
+__device__ __forceinline__ void pe_to_frags_f16(const PE& pe, const float (&x)[3], int h, h8 (&f)[3]) {
+#pragma unroll
+  for (int q = 0; q < 24; ++q) f[q >> 3][q & 7] = (_Float16)pe.v[q];
+  if (h == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      _Float16 hi = (_Float16)x[c];
+      f[0][c] = hi;
+      f[2][5 + c] = (_Float16)(x[c] - (float)hi);
+    }
+  }
+}
+
+static inline int avc_div_up(int a, int b) { return (a + b - 1) / b; }
+
+// error plumbing for the C ABI
+extern "C" const char* avc_last_error();
+void avc_set_error(const char* msg);
+int avc_check_launch(const char* what);

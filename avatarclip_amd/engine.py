@@ -1,0 +1,264 @@
+"""Device-side driver of the fused gfx950 kernels: parameter packing, kernel launches through the C ABI
+(include/avc.h via ctypes) and the autograd.Function that makes render_core differentiable.
+
+There is deliberately no eager/CPU fallback in this file: without libavc.so or without a GPU the calls raise.
+"""
+import ctypes
+import weakref
+
+import numpy as np
+import torch
+
+from . import lib as L
+from . import packing as PK
+
+
+class _DevLayout:
+    """device copies of the index tables of packing.Layout."""
+
+    _cache = {}
+
+    def __init__(self, lay: PK.Layout, device):
+        t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        self.lay = lay
+        self.idx16 = t(lay.idx16)
+        self.scale16 = t(lay.scale16)
+        self.idx32 = t(lay.idx32)
+        self.scale32 = t(lay.scale32)
+        self.un_src = t(lay.un_src)
+        self.un_tgt = t(lay.un_tgt)
+        self.un_scale = t(lay.un_scale)
+        self.ub_src = t(lay.ub_src)
+        self.ub_tgt = t(lay.ub_tgt)
+        self._offsets_arr = (ctypes.c_int * PK.OFF_COUNT)(*[int(v) for v in lay.offsets])
+        self.offsets = ctypes.cast(self._offsets_arr, ctypes.c_void_p)
+
+    @classmethod
+    def get(cls, spec, device):
+        key = (spec.H, spec.NMID, spec.NCMID, str(device))
+        if key not in cls._cache:
+            cls._cache[key] = cls(PK.layout_for(spec), device)
+        return cls._cache[key]
+
+
+class Packed:
+    """Packed parameter blobs of one optimisation step."""
+
+    def __init__(self, dl: _DevLayout, flatP: torch.Tensor):
+        pz = torch.cat([flatP.detach().float(), flatP.new_zeros(1)])
+        w = pz[dl.idx16] * dl.scale16
+        self.w_f16 = w.to(torch.float16).contiguous()
+        self.w_bf16 = w.to(torch.bfloat16).contiguous()
+        self.tab = (pz[dl.idx32] * dl.scale32).contiguous()
+        self.dl = dl
+
+
+def flatten_dense(sdf_net, col_net, spec: PK.NetSpec) -> torch.Tensor:
+    """Flat differentiable vector of every dense weight in packing.param_shapes order."""
+    parts = []
+    for W, b in sdf_net.dense():
+        parts += [W.reshape(-1), b.reshape(-1)]
+    if col_net is not None:
+        for W, b in col_net.dense():
+            parts += [W.reshape(-1), b.reshape(-1)]
+    else:
+        lay = PK.layout_for(spec)
+        n_sdf = sum(int(np.prod(s)) for n, s in lay.shapes if n.startswith("sdf."))
+        parts.append(parts[0].new_zeros(lay.nparam - n_sdf))
+    return torch.cat(parts)
+
+
+class Engine:
+    _by_net = weakref.WeakKeyDictionary()
+    MAX_BWD_WAVES = 1024          # 256 CUs x 4 wavefronts (one per SIMD: the backward kernel uses the full RF)
+    PANEL_BYTES_BUDGET = 12 << 30  # weight-gradient operand panels per chunk of points
+
+    def __init__(self, spec: PK.NetSpec, device):
+        if device.type != "cuda":
+            raise RuntimeError("avatarclip_amd runs its hot path on an MI355X; got device %s (no CPU fallback)" % device)
+        self.spec = spec
+        self.device = device
+        self.lib = L.load()
+        self.dl = _DevLayout.get(spec, device)
+        self.net = spec.net_id
+        assert self.lib.avc_num_offsets() == PK.OFF_COUNT
+        self.ptiles = self.lib.avc_bwd_panel_tiles(self.net)
+        assert self.ptiles == self.dl.lay.panel["TILES"], "panel layout mismatch between packing.py and avc_mlp_bwd.hip"
+        self.scr_bytes = self.lib.avc_bwd_scratch_bytes_per_wave(self.net)
+        assert self.scr_bytes == self.dl.lay.scratch_ksteps * 1024
+        self._scratch = None
+        self._panels = None
+        self._packed_key = None
+        self._packed = None
+
+    @classmethod
+    def for_networks(cls, sdf_net, col_net):
+        eng = cls._by_net.get(sdf_net)
+        if eng is None:
+            col_conf = col_net.conf if col_net is not None else dict(
+                d_hidden=sdf_net.conf["d_hidden"], n_layers=2 if sdf_net.conf["d_hidden"] == 256 else 1,
+                mode="no_view_dir", multires_view=0)
+            spec = PK.spec_from_conf(sdf_net.conf, col_conf)
+            eng = cls(spec, next(sdf_net.parameters()).device)
+            cls._by_net[sdf_net] = eng
+        return eng
+
+    # ------------------------------------------------------------------ packing
+    def pack(self, flatP: torch.Tensor) -> Packed:
+        return Packed(self.dl, flatP)
+
+    def _bufs(self, nblk_chunk):
+        if self._scratch is None:
+            self._scratch = torch.empty(self.MAX_BWD_WAVES * self.scr_bytes, dtype=torch.uint8, device=self.device)
+        need = nblk_chunk * self.ptiles * 2048
+        if self._panels is None or self._panels.numel() < need:
+            self._panels = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._scratch, self._panels
+
+    # ------------------------------------------------------------------ forward launches
+    def sdf_rays(self, pk: Packed, rays_o, rays_d, z, sdf_out=None, slot=None, ld_out=0):
+        R, S = z.shape
+        if sdf_out is None:
+            sdf_out = torch.empty(R, S, device=self.device, dtype=torch.float32)
+        L.check(self.lib.avc_sdf_forward(self.net, None, L.ptr(rays_o), L.ptr(rays_d), L.ptr(z), S, z.stride(0), R * S,
+                                         L.ptr(pk.w_f16), L.ptr(pk.tab), self.dl.offsets, L.ptr(sdf_out),
+                                         L.ptr(slot), ld_out, L.stream()), "avc_sdf_forward")
+        return sdf_out
+
+    def sdf_pts(self, pk: Packed, pts):
+        pts = pts.contiguous().float()
+        out = torch.empty(pts.shape[0], 1, device=self.device, dtype=torch.float32)
+        L.check(self.lib.avc_sdf_forward(self.net, L.ptr(pts), None, None, None, 1, 1, pts.shape[0], L.ptr(pk.w_f16),
+                                         L.ptr(pk.tab), self.dl.offsets, L.ptr(out), None, 0, L.stream()),
+                "avc_sdf_forward")
+        return out
+
+    def upsample_step(self, rays_o, rays_d, z, sdf, m, inv_s):
+        R, n = z.shape
+        z_out = torch.empty(R, n + m, device=self.device, dtype=torch.float32)
+        sdf_out = torch.empty(R, n + m, device=self.device, dtype=torch.float32)
+        z_new = torch.empty(R, m, device=self.device, dtype=torch.float32)
+        slot = torch.empty(R, m, device=self.device, dtype=torch.int32)
+        L.check(self.lib.avc_upsample_step(L.ptr(rays_o), L.ptr(rays_d), L.ptr(z), L.ptr(sdf), R, n, m, float(inv_s),
+                                           L.ptr(z_out), L.ptr(sdf_out), L.ptr(z_new), L.ptr(slot), L.stream()),
+                "avc_upsample_step")
+        return z_out, sdf_out, z_new, slot
+
+    def points_fwd(self, pk: Packed, rays_o, rays_d, z, sample_dist):
+        R, S = z.shape
+        N = R * S
+        sdf = torch.empty(R, S, device=self.device, dtype=torch.float32)
+        nrm = torch.empty(R, S, 3, device=self.device, dtype=torch.float32)
+        rgb = torch.empty(R, S, 6, device=self.device, dtype=torch.float32)
+        L.check(self.lib.avc_render_points_fwd(self.net, None, L.ptr(rays_o), L.ptr(rays_d), L.ptr(z), S, z.stride(0),
+                                               float(sample_dist), N, L.ptr(pk.w_f16), L.ptr(pk.tab), self.dl.offsets,
+                                               L.ptr(sdf), L.ptr(nrm), L.ptr(rgb), L.stream()), "avc_render_points_fwd")
+        return sdf, nrm, rgb
+
+    def composite_fwd(self, sdf, nrm, rgb, z, rays_o, rays_d, inv_s, sample_dist, cos_anneal, bg, bg_mode):
+        R, S = z.shape
+        dev, f32 = self.device, torch.float32
+        color = torch.empty(R, 3, device=dev, dtype=f32)
+        extra = torch.empty(R, 3, device=dev, dtype=f32)
+        weights = torch.empty(R, S, device=dev, dtype=f32)
+        cdf = torch.empty(R, S, device=dev, dtype=f32)
+        mid_z = torch.empty(R, S, device=dev, dtype=f32)
+        inside = torch.empty(R, S, device=dev, dtype=f32)
+        eik = torch.empty(R, 2, device=dev, dtype=f32)
+        L.check(self.lib.avc_composite_fwd(L.ptr(sdf), L.ptr(nrm), L.ptr(rgb), L.ptr(z), L.ptr(rays_o), L.ptr(rays_d), R, S,
+                                           L.ptr(inv_s), float(sample_dist), float(cos_anneal), L.ptr(bg), bg_mode,
+                                           L.ptr(color), L.ptr(extra), L.ptr(weights), L.ptr(cdf), L.ptr(mid_z),
+                                           L.ptr(inside), L.ptr(eik), L.stream()), "avc_composite_fwd")
+        return color, extra, weights, cdf, mid_z, inside, eik
+
+    def composite_bwd(self, sdf, nrm, rgb, z, rays_o, rays_d, inv_s, sample_dist, cos_anneal, bg, bg_mode, d_color,
+                      d_extra, d_w, d_n_up, eik_scale):
+        R, S = z.shape
+        dev, f32 = self.device, torch.float32
+        d_sdf = torch.empty(R, S, device=dev, dtype=f32)
+        d_n = torch.empty(R, S, 3, device=dev, dtype=f32)
+        d_rgb = torch.empty(R, S, 6, device=dev, dtype=f32)
+        d_inv = torch.empty(R, device=dev, dtype=f32)
+        L.check(self.lib.avc_composite_bwd(L.ptr(sdf), L.ptr(nrm), L.ptr(rgb), L.ptr(z), L.ptr(rays_o), L.ptr(rays_d), R, S,
+                                           L.ptr(inv_s), float(sample_dist), float(cos_anneal), L.ptr(bg), bg_mode,
+                                           L.ptr(d_color), L.ptr(d_extra), L.ptr(d_w), L.ptr(d_n_up), L.ptr(eik_scale),
+                                           L.ptr(d_sdf), L.ptr(d_n), L.ptr(d_rgb), L.ptr(d_inv), L.stream()),
+                "avc_composite_bwd")
+        return d_sdf, d_n, d_rgb, d_inv
+
+    # ------------------------------------------------------------------ backward of the point MLP
+    def points_bwd(self, pk: Packed, rays_o, rays_d, z, sample_dist, d_sdf, d_n, d_rgb):
+        """returns the flat dense gradient [nparam] (fp32)."""
+        lay = self.dl.lay
+        R, S = z.shape
+        per_ray_blocks = S / 32.0
+        max_blocks = max(1, self.PANEL_BYTES_BUDGET // (self.ptiles * 2048))
+        rays_per_chunk = max(1, int(max_blocks / per_ray_blocks) - 1)
+        rays_per_chunk = min(rays_per_chunk, R)
+        nblk_max = (rays_per_chunk * S + 31) // 32
+        scratch, panels = self._bufs(nblk_max)
+        gout = torch.zeros(lay.gout_size, device=self.device, dtype=torch.float32)
+        gbias = torch.zeros(max(lay.gbias_size, 1), device=self.device, dtype=torch.float32)
+        st = L.stream()
+        esz = 4
+        for r0 in range(0, R, rays_per_chunk):
+            r1 = min(R, r0 + rays_per_chunk)
+            npts = (r1 - r0) * S
+            nblk = (npts + 31) // 32
+            L.check(self.lib.avc_render_points_bwd(
+                self.net, None, rays_o.data_ptr() + r0 * 3 * esz, rays_d.data_ptr() + r0 * 3 * esz,
+                z.data_ptr() + r0 * z.stride(0) * esz, S, z.stride(0), float(sample_dist), npts, L.ptr(pk.w_f16),
+                L.ptr(pk.w_bf16), L.ptr(pk.tab), self.dl.offsets, d_sdf.data_ptr() + r0 * S * esz,
+                d_n.data_ptr() + r0 * S * 3 * esz, d_rgb.data_ptr() + r0 * S * 6 * esz, L.ptr(panels),
+                self.MAX_BWD_WAVES, L.ptr(scratch), st), "avc_render_points_bwd")
+            nsplit = max(1, min(nblk, 1024 // 8))
+            for (pa, ta, pb, tb, out_off, bias_off) in lay.pairs:
+                bptr = gbias.data_ptr() + bias_off * 4 if bias_off >= 0 else None
+                L.check(self.lib.avc_weight_grad(L.ptr(panels), self.ptiles, pa, ta, pb, tb, nblk,
+                                                 gout.data_ptr() + out_off * 4, bptr, nsplit, st), "avc_weight_grad")
+        grad = torch.zeros(lay.nparam, device=self.device, dtype=torch.float32)
+        grad.index_add_(0, self.dl.un_tgt, gout[self.dl.un_src] * self.dl.un_scale)
+        if lay.gbias_size:
+            grad.index_add_(0, self.dl.ub_tgt, gbias[self.dl.ub_src])
+        return grad
+
+
+class RenderCoreFn(torch.autograd.Function):
+    """render_core (renderer.py:195-300) on fixed z_vals: fused point MLP + compositing, differentiable wrt the
+    flat dense parameter vector and inv_s."""
+
+    @staticmethod
+    def forward(ctx, flatP, inv_s, eng, rays_o, rays_d, z_vals, sample_dist, cos_anneal, bg, bg_mode):
+        pk = eng.pack(flatP)
+        inv_s_d = inv_s.detach().float().contiguous()
+        sdf, nrm, rgb = eng.points_fwd(pk, rays_o, rays_d, z_vals, sample_dist)
+        color, extra, weights, cdf, mid_z, inside, eik = eng.composite_fwd(
+            sdf, nrm, rgb, z_vals, rays_o, rays_d, inv_s_d, sample_dist, cos_anneal, bg, bg_mode)
+        eik_den = eik[:, 1].sum() + 1e-5
+        gerr = eik[:, 0].sum() / eik_den
+        ctx.eng, ctx.pk = eng, pk
+        ctx.consts = (sample_dist, cos_anneal, bg_mode)
+        ctx.save_for_backward(rays_o, rays_d, z_vals, sdf, nrm, rgb, inv_s_d, eik_den, bg if bg is not None else inv_s_d)
+        ctx.has_bg = bg is not None
+        ctx.mark_non_differentiable(cdf, mid_z, inside, sdf)
+        return color, extra, weights, nrm, gerr, cdf, mid_z, inside, sdf
+
+    @staticmethod
+    def backward(ctx, d_color, d_extra, d_weights, d_nrm, d_gerr, *unused):
+        eng, pk = ctx.eng, ctx.pk
+        rays_o, rays_d, z_vals, sdf, nrm, rgb, inv_s_d, eik_den, bg = ctx.saved_tensors
+        if not ctx.has_bg:
+            bg = None
+        sample_dist, cos_anneal, bg_mode = ctx.consts
+        R, S = z_vals.shape
+        zeros = lambda *s: torch.zeros(*s, device=z_vals.device, dtype=torch.float32)
+        d_color = d_color.contiguous().float() if d_color is not None else zeros(R, 3)
+        d_extra = d_extra.contiguous().float() if d_extra is not None else zeros(R, 3)
+        d_weights = d_weights.contiguous().float() if d_weights is not None else zeros(R, S)
+        d_nrm = d_nrm.contiguous().float() if d_nrm is not None else None
+        d_gerr = d_gerr if d_gerr is not None else zeros(())
+        eik_scale = (d_gerr.float() / eik_den).reshape(1).contiguous()
+        d_sdf, d_n, d_rgb, d_inv = eng.composite_bwd(sdf, nrm, rgb, z_vals, rays_o, rays_d, inv_s_d, sample_dist,
+                                                     cos_anneal, bg, bg_mode, d_color, d_extra, d_weights, d_nrm, eik_scale)
+        grad = eng.points_bwd(pk, rays_o, rays_d, z_vals, sample_dist, d_sdf, d_n, d_rgb)
+        return grad, d_inv.sum().reshape(1), None, None, None, None, None, None, None, None

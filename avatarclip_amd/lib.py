@@ -1,0 +1,75 @@
+"""ctypes binding of libavc.so (the C ABI declared in include/avc.h).  No fallback: if the library is missing
+or a call fails, an exception is raised."""
+import ctypes
+import os
+
+import torch
+
+from . import build as _build
+
+_lib = None
+
+c_int, c_long, c_float, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
+P = c_void_p
+
+_SIGS = {
+    "avc_version": (c_int, []),
+    "avc_num_offsets": (c_int, []),
+    "avc_bwd_panel_tiles": (c_int, [c_int]),
+    "avc_bwd_scratch_bytes_per_wave": (c_long, [c_int]),
+    "avc_sdf_forward": (c_int, [c_int, P, P, P, P, c_int, c_int, c_long, P, P, P, P, P, c_int, P]),
+    "avc_upsample_step": (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, P, P, P, P, P]),
+    "avc_render_points_fwd": (c_int, [c_int, P, P, P, P, c_int, c_int, c_float, c_long, P, P, P, P, P, P, P]),
+    "avc_composite_fwd": (c_int, [P, P, P, P, P, P, c_int, c_int, P, c_float, c_float, P, c_int, P, P, P, P, P, P, P, P]),
+    "avc_composite_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, P, c_float, c_float, P, c_int, P, P, P, P, P, P, P,
+                                  P, P, P]),
+    "avc_render_points_bwd": (c_int, [c_int, P, P, P, P, c_int, c_int, c_float, c_long, P, P, P, P, P, P, P, P, c_long,
+                                      P, P]),
+    "avc_probe_mfma": (c_int, [P, P, P, P, P, P, P]),
+    "avc_weight_grad": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_long, P, P, c_int, P]),
+}
+_OPTIONAL = {}
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError("libavc.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                           "there is no CPU fallback for the HIP hot path")
+    lib = ctypes.CDLL(path)
+    lib.avc_last_error.restype = ctypes.c_char_p
+    lib.avc_last_error.argtypes = []
+    for name, (res, args) in list(_SIGS.items()) + list(_OPTIONAL.items()):
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def register_optional(sigs):
+    _OPTIONAL.update(sigs)
+
+
+def ptr(t):
+    """device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "HIP kernels need contiguous device tensors"
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError("libavc %s failed: %s" % (what, load().avc_last_error().decode()))

@@ -1,0 +1,95 @@
+/* avc.h -- C ABI of libavc.so, the MI355X (gfx950) implementation of the AvatarCLIP AppearanceGen hot path.
+ *
+ * The reference (hongfz16/AvatarCLIP) has no FFI of its own: the hot path is the Python call chain
+ *   AvatarGen/AppearanceGen/main.py:418-420   Runner.train_clip -> NeuSRenderer.render
+ *   AvatarGen/AppearanceGen/models/renderer.py:302-397 (render), :133-193 (up_sample/cat_z_vals), :195-300 (render_core)
+ *   AvatarGen/AppearanceGen/models/fields.py:72-107,154-185 (SDFNetwork / RenderingNetwork)
+ *   AvatarGen/AppearanceGen/main.py:512 (perceptor.encode_image -- OpenAI CLIP ViT-B/32, un-vendored)
+ * Each entry point below names the reference lines it replaces.  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions: every pointer is a DEVICE pointer (hipMalloc / torch allocation) unless marked host; buffers are
+ * caller-allocated, no ownership transfer; `stream` is a hipStream_t; all kernels are enqueued on it and the
+ * call returns without synchronising.  Return value 0 = ok, otherwise avc_last_error() describes the failure.
+ * No CPU fallback exists: with no GPU the calls fail.
+ */
+#ifndef AVC_H
+#define AVC_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVC_NET_FULL 0  /* confs/examples (all 144):   SDF 39-256-256-256-217(+39)-257, colour 262-256-256-{3,3} */
+#define AVC_NET_SMALL 1 /* confs/examples_small:        SDF 39-128-128-89(+39)-129,     colour 134-128-{3,3}     */
+
+const char* avc_last_error(void);
+int avc_version(void);
+/* number of int32 slots in the `offs` arrays below (== OFF_COUNT of csrc/avc_common.h) */
+int avc_num_offsets(void);
+
+/* SDFNetwork.sdf (fields.py:90-91) without autograd: renderer.py:337-338 (coarse), :187 (new samples),
+ * :403 (extract_geometry query).  Points are either pts[N,3] or rays_o/rays_d[R,3] + z[R,ldz] (S per ray).
+ * If slot != NULL the value of sample (ray,j) is scattered to sdf_out[ray*ld_out + slot[ray*S+j]]
+ * (the merge of cat_z_vals, renderer.py:179-193). wf16/tab/offs: packed parameters (avatarclip_amd/packing.py). */
+int avc_sdf_forward(int net, const float* pts, const float* rays_o, const float* rays_d, const float* z, int S,
+                    int ldz, long npts, const void* wf16, const float* tab, const int* offs /* host */,
+                    float* sdf_out, const int* slot, int ld_out, void* stream);
+
+/* One step of NeuSRenderer.up_sample + sample_pdf(det=True) + the sort/merge of cat_z_vals
+ * (renderer.py:133-177, 39-69, 179-193) for R rays with n current samples, producing m new ones.
+ * z_out/sdf_out [R, n+m] receive the merged z and the old sdf values at their merged positions; z_new/slot_new
+ * [R,m] the new depths and their positions in the merged row (sdf of those is filled by avc_sdf_forward). */
+int avc_upsample_step(const float* rays_o, const float* rays_d, const float* z_in, const float* sdf_in, int R,
+                      int n, int m, float inv_s, float* z_out, float* sdf_out, float* z_new, int* slot_new,
+                      void* stream);
+
+/* sdf_network(pts) + sdf_network.gradient(pts) + color_network(...) of render_core (renderer.py:221-232) at the
+ * section mid-points of z[R,S] (or at pts[N,3]): sdf[N], normal[N,3] (= d sdf/dx), rgb[N,6] = sigmoid([rgb ; extra]). */
+int avc_render_points_fwd(int net, const float* pts, const float* rays_o, const float* rays_d, const float* z,
+                          int S, int ldz, float sample_dist, long npts, const void* wf16, const float* tab,
+                          const int* offs /* host */, float* sdf_out, float* normal_out, float* rgb_out, void* stream);
+
+/* NeuS alpha + compositing of render_core (renderer.py:234-286), one wavefront per ray.
+ * bg_mode 0: none, 1: bg[3] shared, 2: bg[R] grey per ray (main.py:387-415); background is composited into
+ * `extra` only (renderer.py:277-281).  Outputs: color[R,3], extra[R,3], weights[R,S], cdf[R,S], mid_z[R,S],
+ * inside[R,S], eik[R,2] = per-ray (sum relax*(|n|-1)^2, sum relax). */
+int avc_composite_fwd(const float* sdf, const float* normal, const float* rgb, const float* z, const float* rays_o,
+                      const float* rays_d, int R, int S, const float* inv_s /* device scalar */, float sample_dist,
+                      float cos_anneal, const float* bg, int bg_mode, float* color, float* extra, float* weights,
+                      float* cdf, float* mid_z, float* inside, float* eik, void* stream);
+
+/* Reverse of avc_composite_fwd.  Upstream: d_color[R,3], d_extra[R,3], d_weights[R,S], d_normal_up[R,S,3] (may be
+ * NULL), eik_scale = d(loss)/d(eik) / (sum relax + 1e-5) (device scalar).  Outputs: d_sdf[R,S], d_normal[R,S,3],
+ * d_rgb[R,S,6], d_inv_s[R] (per-ray partial of d loss / d inv_s). */
+int avc_composite_bwd(const float* sdf, const float* normal, const float* rgb, const float* z, const float* rays_o,
+                      const float* rays_d, int R, int S, const float* inv_s, float sample_dist, float cos_anneal,
+                      const float* bg, int bg_mode, const float* d_color, const float* d_extra,
+                      const float* d_weights, const float* d_normal_up, const float* eik_scale, float* d_sdf,
+                      float* d_normal, float* d_rgb, float* d_inv_s, void* stream);
+
+/* Backward of avc_render_points_fwd wrt every dense weight (autograd incl. the double backward of
+ * SDFNetwork.gradient, fields.py:96-107; main.py:537).  Recomputes the forward, runs the second-order and the
+ * reverse sweep and writes the bf16 operand panels of every weight-gradient product to `panels`
+ * (avc_bwd_panel_tiles(net) tiles of 2 KiB per 32-point block); avc_weight_grad then contracts them over the
+ * points.  `scratch` holds max_waves * avc_bwd_scratch_bytes_per_wave(net) bytes. */
+int avc_bwd_panel_tiles(int net);
+long avc_bwd_scratch_bytes_per_wave(int net);
+int avc_render_points_bwd(int net, const float* pts, const float* rays_o, const float* rays_d, const float* z,
+                          int S, int ldz, float sample_dist, long npts, const void* wf16, const void* wbf16,
+                          const float* tab, const int* offs /* host */, const float* d_sdf, const float* d_normal,
+                          const float* d_rgb, void* panels, long max_waves, float* scratch, void* stream);
+
+/* out[ta,tb,64,16] += sum over `nblk` 32-point blocks of A-panel tile (pa+ta) x B-panel tile (pb+tb), K = points;
+ * lane (n,h), reg r of tile (ta,tb) is dW[32 ta + (r&3)+8(r>>2)+4h][32 tb + n].  bias_out (may be NULL)
+ * receives sum_points A[:, 32 ta + n].  nsplit = split-K factor (partials combined with fp32 atomics). */
+int avc_weight_grad(const void* panels, int ptiles, int pa, int ta, int pb, int tb, long nblk, float* out,
+                    float* bias_out, int nsplit, void* stream);
+
+/* test hook: one v_mfma_f32_32x32x16_{f16,bf16} on caller-provided per-lane fragments (64 lanes x 8 / x16) */
+int avc_probe_mfma(const void* a_f16, const void* b_f16, float* d, const void* a_bf16, const void* b_bf16, float* d_bf,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,168 @@
+"""CLIP ViT-B/32 image encoder on the gfx950 kernels -- drop-in for `perceptor.encode_image`
+(AvatarGen/AppearanceGen/main.py:259-260,512,518,524; upstream: OpenAI clip/model.py VisionTransformer, un-vendored).
+
+All GEMMs (patch embedding, in_proj, out_proj, c_fc, c_proj, visual.proj) run in avc_vit_linear (bf16 MFMA, fp32
+accumulate; the reference runs CLIP in fp16 on GPU), attention in avc_vit_attention_*.  Weights are frozen
+(`requires_grad_(False)`, main.py:260): the backward only propagates to the pixels, re-using the same GEMM kernel on
+the packed transposes.  LayerNorm / residual bookkeeping are torch elementwise ops under autograd.
+Accepts an OpenAI-format state dict (`visual.*` keys, e.g. torch.jit.load('ViT-B-32.pt').state_dict()).
+"""
+import math
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+
+from . import lib as L
+
+WIDTH, LAYERS, HEADS, PATCH, RES, EMBED = 768, 12, 12, 32, 224, 512
+TOKENS = (RES // PATCH) ** 2 + 1
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def pack_weight(w: torch.Tensor) -> torch.Tensor:
+    """[N,K] -> bf16 [N/32][K/16][64][8] in MFMA B-operand order (lane (n,h) holds W[32t+n][16s+8h+j])."""
+    N, K = w.shape
+    assert N % 32 == 0 and K % 16 == 0
+    p = w.reshape(N // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+    return p.to(torch.bfloat16).reshape(-1)
+
+
+class _Lin:
+    def __init__(self, w, b, dev):
+        w = w.float().to(dev)
+        self.N, self.K = w.shape
+        self.wp = pack_weight(w)
+        self.wtp = pack_weight(w.t().contiguous())
+        self.b = None if b is None else b.float().to(dev).contiguous()
+
+
+def _linear_raw(x2d, wp, bias, residual, N, K, act, want_pre):
+    lib = L.load()
+    M = x2d.shape[0]
+    y = torch.empty(M, N, device=x2d.device, dtype=torch.float32)
+    pre = torch.empty_like(y) if (act and want_pre) else None
+    for m0 in range(0, M, 128):
+        m1 = min(M, m0 + 128)
+        off = lambda t, cols: None if t is None else t.data_ptr() + m0 * cols * 4
+        L.check(lib.avc_vit_linear(off(x2d, K), L.ptr(wp), L.ptr(bias), off(residual, N), off(y, N), off(pre, N),
+                                   m1 - m0, N, K, act, L.stream()), "avc_vit_linear")
+    return y, pre
+
+
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, lin, act, residual):
+        shp = x.shape
+        x2 = x.reshape(-1, lin.K).contiguous().float()
+        r2 = None if residual is None else residual.reshape(-1, lin.N).contiguous().float()
+        y, pre = _linear_raw(x2, lin.wp, lin.b, r2, lin.N, lin.K, act, x.requires_grad or True)
+        ctx.lin, ctx.act, ctx.has_res = lin, act, residual is not None
+        ctx.save_for_backward(pre if pre is not None else y.new_zeros(1))
+        return y.reshape(*shp[:-1], lin.N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lin = ctx.lin
+        shp = dy.shape
+        d2 = dy.reshape(-1, lin.N).contiguous().float()
+        if ctx.act:
+            (pre,) = ctx.saved_tensors
+            s = torch.sigmoid(1.702 * pre)
+            d2 = d2 * (s + 1.702 * pre * s * (1 - s))
+        dx, _ = _linear_raw(d2.contiguous(), lin.wtp, None, None, lin.K, lin.N, 0, False)
+        dres = dy if ctx.has_res else None
+        return dx.reshape(*shp[:-1], lin.K), None, None, dres
+
+
+class AttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv):
+        lib = L.load()
+        B, T, _ = qkv.shape
+        qkv = qkv.contiguous().float()
+        out = torch.empty(B, T, WIDTH, device=qkv.device, dtype=torch.float32)
+        L.check(lib.avc_vit_attention_fwd(L.ptr(qkv), L.ptr(out), B, T, WIDTH, HEADS, L.stream()), "avc_vit_attention_fwd")
+        ctx.save_for_backward(qkv)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = L.load()
+        (qkv,) = ctx.saved_tensors
+        B, T, _ = qkv.shape
+        dout = dout.contiguous().float()
+        dqkv = torch.empty_like(qkv)
+        L.check(lib.avc_vit_attention_bwd(L.ptr(qkv), L.ptr(dout), L.ptr(dqkv), B, T, WIDTH, HEADS, L.stream()),
+                "avc_vit_attention_bwd")
+        return dqkv
+
+
+class ClipVisionB32:
+    """`perceptor` stand-in: .encode_image(x[B,3,224,224]) -> [B,512] (differentiable wrt x only)."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda"):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("ClipVisionB32 runs on the MI355X kernels only (no CPU fallback)")
+        sd = {k: v for k, v in state_dict.items() if k.startswith("visual.")}
+        f = lambda k: sd[k].float().to(dev).contiguous()
+        self.device = dev
+        self.conv = _Lin(sd["visual.conv1.weight"].reshape(WIDTH, -1), None, dev)
+        self.cls = f("visual.class_embedding")
+        self.pos = f("visual.positional_embedding")
+        self.ln_pre = (f("visual.ln_pre.weight"), f("visual.ln_pre.bias"))
+        self.ln_post = (f("visual.ln_post.weight"), f("visual.ln_post.bias"))
+        self.blocks = []
+        for i in range(LAYERS):
+            p = "visual.transformer.resblocks.%d." % i
+            self.blocks.append(dict(
+                ln1=(f(p + "ln_1.weight"), f(p + "ln_1.bias")), ln2=(f(p + "ln_2.weight"), f(p + "ln_2.bias")),
+                qkv=_Lin(sd[p + "attn.in_proj_weight"], sd[p + "attn.in_proj_bias"], dev),
+                out=_Lin(sd[p + "attn.out_proj.weight"], sd[p + "attn.out_proj.bias"], dev),
+                fc=_Lin(sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"], dev),
+                proj=_Lin(sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"], dev)))
+        self.proj = _Lin(sd["visual.proj"].t().contiguous(), None, dev)
+
+    def eval(self):
+        return self
+
+    def requires_grad_(self, flag=False):
+        return self
+
+    def cuda(self):
+        return self
+
+    def encode_image(self, image: torch.Tensor) -> torch.Tensor:
+        B = image.shape[0]
+        # conv1 (32x32, stride 32, no bias) == GEMM over flattened patches in (c, ky, kx) order
+        x = image.float().reshape(B, 3, RES // PATCH, PATCH, RES // PATCH, PATCH).permute(0, 2, 4, 1, 3, 5)
+        x = x.reshape(B, (RES // PATCH) ** 2, 3 * PATCH * PATCH)
+        x = LinearFn.apply(x, self.conv, 0, None)
+        x = torch.cat([self.cls.expand(B, 1, WIDTH), x], dim=1) + self.pos
+        x = F.layer_norm(x, (WIDTH,), self.ln_pre[0], self.ln_pre[1], 1e-5)
+        for blk in self.blocks:
+            y = F.layer_norm(x, (WIDTH,), blk["ln1"][0], blk["ln1"][1], 1e-5)
+            a = AttentionFn.apply(LinearFn.apply(y, blk["qkv"], 0, None))
+            x = LinearFn.apply(a, blk["out"], 0, x)                      # residual fused in the epilogue
+            y = F.layer_norm(x, (WIDTH,), blk["ln2"][0], blk["ln2"][1], 1e-5)
+            y = LinearFn.apply(y, blk["fc"], 1, None)                    # QuickGELU fused
+            x = LinearFn.apply(y, blk["proj"], 0, x)
+        x = F.layer_norm(x[:, 0, :], (WIDTH,), self.ln_post[0], self.ln_post[1], 1e-5)
+        return LinearFn.apply(x, self.proj, 0, None)
+
+    def encode_text(self, tokens):
+        raise NotImplementedError("the text tower runs once per prompt at start-up (main.py:273-288) and is outside the "
+                                  "hot path; supply the cached 512-d prompt embedding instead (SURVEY.md §8 row f-3)")
+
+
+def clip_preprocess(img_hw3: torch.Tensor) -> torch.Tensor:
+    """main.py:261-267,510-511: RandomResizedCrop(224, scale=(1,1)) of a square image == bilinear resize
+    (align_corners=False, no antialias); RandomPerspective(p=0) == identity; then Normalize."""
+    x = img_hw3.permute(2, 0, 1).unsqueeze(0)
+    if x.shape[-1] != RES or x.shape[-2] != RES:
+        x = F.interpolate(x, size=(RES, RES), mode="bilinear", align_corners=False)
+    mean = torch.tensor(CLIP_MEAN, device=x.device, dtype=x.dtype).view(1, 3, 1, 1)
+    std = torch.tensor(CLIP_STD, device=x.device, dtype=x.dtype).view(1, 3, 1, 1)
+    return (x - mean) / std

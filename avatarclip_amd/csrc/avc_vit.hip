@@ -1,0 +1,243 @@
+// CLIP ViT-B/32 image-encoder kernels (perceptor.encode_image, main.py:512; OpenAI clip/model.py VisionTransformer).
+//   avc_vit_linear   Y[M,N] = act(X[M,K] W[N,K]^T + b) (+ residual)   -- bf16 MFMA 32x32x16, fp32 accumulate.
+//                    M = 50..100 tokens: the GEMM is weight-streaming bound, so W is pre-packed in B-operand
+//                    fragment order (one coalesced 16-B load per lane per k-step), the K range is split over the
+//                    4 wavefronts of a workgroup and reduced through LDS, one workgroup per 32 output columns.
+//                    The same kernel computes dX = dY W with the pre-packed W^T (weights are frozen: no dW).
+//   avc_vit_attention_fwd / _bwd   12-head attention over 50 tokens, one workgroup per (image, head), fp32 in LDS.
+#include "avc_common.h"
+#include "../../include/avc.h"
+
+#define VIT_MAX_MT 4   // up to 128 rows (tokens) per launch
+
+template <int MT>
+__global__ __launch_bounds__(256) void vit_linear_kernel(const float* __restrict__ X, const b8* __restrict__ Wp,
+                                                         const float* __restrict__ bias, const float* __restrict__ res,
+                                                         float* __restrict__ Y, float* __restrict__ Ypre, int M, int N, int K,
+                                                         int act) {
+  __shared__ float red[3][MT][64][16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int n = lane & 31, h = lane >> 5;
+  const int t = blockIdx.x;           // output column tile
+  const int KS = K >> 4;              // k-steps of 16
+  const int ks_per = (KS + 3) >> 2;
+  const int s0 = wv * ks_per, s1 = min(KS, s0 + ks_per);
+  facc acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+  const b8* wp = Wp + ((long)t * KS) * 64 + lane;
+  for (int s = s0; s < s1; ++s) {
+    const b8 w = wp[(long)s * 64];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int row = 32 * m + n;   // as A operand: lane (i = token, h) holds X[token][16 s + 8 h + j]
+      b8 xf;
+      if (row < M) {
+        const f4* xp = reinterpret_cast<const f4*>(X + (long)row * K + 16 * s + 8 * h);
+        const f4 a = xp[0], b = xp[1];
+        xf[0] = (__bf16)a[0]; xf[1] = (__bf16)a[1]; xf[2] = (__bf16)a[2]; xf[3] = (__bf16)a[3];
+        xf[4] = (__bf16)b[0]; xf[5] = (__bf16)b[1]; xf[6] = (__bf16)b[2]; xf[7] = (__bf16)b[3];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xf[j] = (__bf16)0.f;
+      }
+      acc[m] = MF<b8>::mma(xf, w, acc[m]);
+    }
+  }
+  if (wv > 0) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[wv - 1][m][lane][r] = acc[m][r];
+  }
+  __syncthreads();
+  if (wv == 0) {
+    const int col = 32 * t + n;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < M) {
+          float v = acc[m][r] + red[0][m][lane][r] + red[1][m][lane][r] + red[2][m][lane][r] + bv;
+          const long o = (long)row * N + col;
+          if (act == 1) {
+            if (Ypre) Ypre[o] = v;
+            v = v * sigmoidf_(1.702f * v);
+          }
+          if (res) v += res[o];
+          Y[o] = v;
+        }
+      }
+    }
+  }
+}
+
+extern "C" int avc_vit_linear(const float* x, const void* w_packed, const float* bias, const float* residual, float* y,
+                              float* y_pre, int M, int N, int K, int act, void* stream) {
+  if (M <= 0) return 0;
+  if ((N & 31) || (K & 15) || M > 32 * VIT_MAX_MT) {
+    avc_set_error("avc_vit_linear: need N % 32 == 0, K % 16 == 0, M <= 128");
+    return 1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(N / 32), block(256);
+  const b8* wp = (const b8*)w_packed;
+  const int mt = (M + 31) / 32;
+  switch (mt) {
+    case 1: hipLaunchKernelGGL((vit_linear_kernel<1>), grid, block, 0, s, x, wp, bias, residual, y, y_pre, M, N, K, act); break;
+    case 2: hipLaunchKernelGGL((vit_linear_kernel<2>), grid, block, 0, s, x, wp, bias, residual, y, y_pre, M, N, K, act); break;
+    case 3: hipLaunchKernelGGL((vit_linear_kernel<3>), grid, block, 0, s, x, wp, bias, residual, y, y_pre, M, N, K, act); break;
+    default: hipLaunchKernelGGL((vit_linear_kernel<4>), grid, block, 0, s, x, wp, bias, residual, y, y_pre, M, N, K, act); break;
+  }
+  return avc_check_launch("avc_vit_linear");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// attention: qkv [B,T,3*W] (q | k | v, head hd at column hd*64), out [B,T,W].  One 64-thread workgroup per (b, head).
+// ---------------------------------------------------------------------------------------------------------
+#define AT_T 50
+#define AT_D 64
+#define AT_LD 65   // +1 padding: thread i reads row i -> conflict-free
+
+__global__ __launch_bounds__(64) void vit_attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, int Wd,
+                                                          int heads, float scale) {
+  __shared__ float Ks[AT_T][AT_LD], Vs[AT_T][AT_LD];
+  const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
+  const int i = threadIdx.x;
+  const float* base = qkv + (long)b * AT_T * 3 * Wd + hd * AT_D;
+  for (int e = threadIdx.x; e < AT_T * AT_D; e += 64) {
+    const int r = e / AT_D, c = e % AT_D;
+    Ks[r][c] = base[(long)r * 3 * Wd + Wd + c];
+    Vs[r][c] = base[(long)r * 3 * Wd + 2 * Wd + c];
+  }
+  __syncthreads();
+  if (i >= AT_T) return;
+  float q[AT_D];
+#pragma unroll
+  for (int c = 0; c < AT_D; ++c) q[c] = base[(long)i * 3 * Wd + c] * scale;
+  float p[AT_T];
+  float mx = -1e30f;
+#pragma unroll
+  for (int j = 0; j < AT_T; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < AT_D; ++c) s += q[c] * Ks[j][c];
+    p[j] = s;
+    mx = fmaxf(mx, s);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < AT_T; ++j) { p[j] = __expf(p[j] - mx); sum += p[j]; }
+  const float inv = 1.f / sum;
+  float o[AT_D];
+#pragma unroll
+  for (int c = 0; c < AT_D; ++c) o[c] = 0.f;
+#pragma unroll
+  for (int j = 0; j < AT_T; ++j) {
+    const float pj = p[j] * inv;
+#pragma unroll
+    for (int c = 0; c < AT_D; ++c) o[c] += pj * Vs[j][c];
+  }
+  float* op = out + ((long)b * AT_T + i) * Wd + hd * AT_D;
+#pragma unroll
+  for (int c = 0; c < AT_D; ++c) op[c] = o[c];
+}
+
+__global__ __launch_bounds__(64) void vit_attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                          float* __restrict__ dqkv, int Wd, int heads, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float (*Ks)[AT_LD] = reinterpret_cast<float (*)[AT_LD]>(sm);
+  float (*Vs)[AT_LD] = Ks + AT_T;
+  float (*Qs)[AT_LD] = Vs + AT_T;
+  float (*Ds)[AT_LD] = Qs + AT_T;                       // dO
+  float (*Ps)[AT_T + 1] = reinterpret_cast<float (*)[AT_T + 1]>(Ds + AT_T);   // P
+  float (*Ss)[AT_T + 1] = Ps + AT_T;                    // dS (already scaled)
+  const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
+  const int i = threadIdx.x;
+  const float* base = qkv + (long)b * AT_T * 3 * Wd + hd * AT_D;
+  const float* dob = dout + (long)b * AT_T * Wd + hd * AT_D;
+  for (int e = threadIdx.x; e < AT_T * AT_D; e += 64) {
+    const int r = e / AT_D, c = e % AT_D;
+    Qs[r][c] = base[(long)r * 3 * Wd + c];
+    Ks[r][c] = base[(long)r * 3 * Wd + Wd + c];
+    Vs[r][c] = base[(long)r * 3 * Wd + 2 * Wd + c];
+    Ds[r][c] = dob[(long)r * Wd + c];
+  }
+  __syncthreads();
+  if (i < AT_T) {
+    // row i of P and dS lives in this thread's own LDS row (no register arrays with run-time indices)
+    float mx = -1e30f;
+    for (int j = 0; j < AT_T; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < AT_D; ++c) s += Qs[i][c] * Ks[j][c];
+      s *= scale;
+      Ps[i][j] = s;
+      mx = fmaxf(mx, s);
+    }
+    float sum = 0.f;
+    for (int j = 0; j < AT_T; ++j) { const float e = __expf(Ps[i][j] - mx); Ps[i][j] = e; sum += e; }
+    const float inv = 1.f / sum;
+    float dsum = 0.f;
+    for (int j = 0; j < AT_T; ++j) {
+      const float pj = Ps[i][j] * inv;
+      Ps[i][j] = pj;
+      float d = 0.f;
+#pragma unroll
+      for (int c = 0; c < AT_D; ++c) d += Ds[i][c] * Vs[j][c];
+      Ss[i][j] = d;
+      dsum += pj * d;
+    }
+    float dq[AT_D];
+#pragma unroll
+    for (int c = 0; c < AT_D; ++c) dq[c] = 0.f;
+    for (int j = 0; j < AT_T; ++j) {
+      const float ds = Ps[i][j] * (Ss[i][j] - dsum) * scale;
+      Ss[i][j] = ds;
+#pragma unroll
+      for (int c = 0; c < AT_D; ++c) dq[c] += ds * Ks[j][c];
+    }
+    float* dqp = dqkv + ((long)b * AT_T + i) * 3 * Wd + hd * AT_D;
+#pragma unroll
+    for (int c = 0; c < AT_D; ++c) dqp[c] = dq[c];
+  }
+  __syncthreads();
+  if (i < AT_T) {
+    const int j = i;
+    float dk[AT_D], dv[AT_D];
+#pragma unroll
+    for (int c = 0; c < AT_D; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
+    for (int r = 0; r < AT_T; ++r) {
+      const float ds = Ss[r][j], pr = Ps[r][j];
+#pragma unroll
+      for (int c = 0; c < AT_D; ++c) { dk[c] += ds * Qs[r][c]; dv[c] += pr * Ds[r][c]; }
+    }
+    float* dkp = dqkv + ((long)b * AT_T + j) * 3 * Wd + Wd + hd * AT_D;
+    float* dvp = dqkv + ((long)b * AT_T + j) * 3 * Wd + 2 * Wd + hd * AT_D;
+#pragma unroll
+    for (int c = 0; c < AT_D; ++c) { dkp[c] = dk[c]; dvp[c] = dv[c]; }
+  }
+}
+
+extern "C" int avc_vit_attention_fwd(const float* qkv, float* out, int B, int T, int width, int heads, void* stream) {
+  if (T != AT_T || width != heads * AT_D) { avc_set_error("avc_vit_attention: built for 50 tokens, head dim 64"); return 1; }
+  hipLaunchKernelGGL(vit_attn_fwd_kernel, dim3(B * heads), dim3(64), 0, (hipStream_t)stream, qkv, out, width, heads, 0.125f);
+  return avc_check_launch("avc_vit_attention_fwd");
+}
+extern "C" int avc_vit_attention_bwd(const float* qkv, const float* dout, float* dqkv, int B, int T, int width, int heads,
+                                     void* stream) {
+  if (T != AT_T || width != heads * AT_D) { avc_set_error("avc_vit_attention: built for 50 tokens, head dim 64"); return 1; }
+  const size_t lds = (4 * AT_T * AT_LD + 2 * AT_T * (AT_T + 1)) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)vit_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(vit_attn_bwd_kernel, dim3(B * heads), dim3(64), lds, (hipStream_t)stream, qkv, dout, dqkv, width, heads,
+                     0.125f);
+  return avc_check_launch("avc_vit_attention_bwd");
+}

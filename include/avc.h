@@ -85,6 +85,17 @@ int avc_render_points_bwd(int net, const float* pts, const float* rays_o, const 
 int avc_weight_grad(const void* panels, int ptiles, int pa, int ta, int pb, int tb, long nblk, float* out,
                     float* bias_out, int nsplit, void* stream);
 
+/* ---- CLIP ViT-B/32 image encoder (perceptor.encode_image, main.py:512,518,524; OpenAI clip/model.py) ----
+ * y[M,N] = act(x[M,K] W^T + bias) (+ residual); W pre-packed bf16 [N/32][K/16][64][8] (lane (n,h): W[32t+n][16s+8h+j]).
+ * act 1 = QuickGELU (y_pre, if given, receives the pre-activation for the backward).  The backward dX = dY W is the same
+ * call with the packed W^T (weights are frozen in AvatarCLIP: main.py:260). M <= 128. */
+int avc_vit_linear(const float* x, const void* w_packed, const float* bias, const float* residual, float* y,
+                   float* y_pre, int M, int N, int K, int act, void* stream);
+/* multi-head self-attention of ResidualAttentionBlock over T=50 tokens, head dim 64: qkv[B,T,3W] -> out[B,T,W] */
+int avc_vit_attention_fwd(const float* qkv, float* out, int B, int T, int width, int heads, void* stream);
+int avc_vit_attention_bwd(const float* qkv, const float* dout, float* dqkv, int B, int T, int width, int heads,
+                          void* stream);
+
 /* test hook: one v_mfma_f32_32x32x16_{f16,bf16} on caller-provided per-lane fragments (64 lanes x 8 / x16) */
 int avc_probe_mfma(const void* a_f16, const void* b_f16, float* d, const void* a_bf16, const void* b_bf16, float* d_bf,
                    void* stream);

@@ -1,0 +1,123 @@
+"""SMPL_Dataset: camera / ray generation with the reference's conventions
+(AvatarGen/AppearanceGen/models/dataset.py:203-347), device-explicit and generalised beyond H=W=256
+(BASELINE configs render at 224^2 and 512^2).  Ray maths runs as torch elementwise ops on the target device.
+"""
+import json
+import os
+
+import numpy as np
+import torch
+
+
+class SMPL_Dataset:
+    def __init__(self, conf=None, device="cuda", H=None, W=None, camera_angle_x=None, load_images=True):
+        """conf: ConfigTree with `data_dir` (NeRF-synthetic layout: transforms_train.json + img/*.png, dataset.py:211-224).
+        Without a data_dir the dataset is purely synthetic: H, W and camera_angle_x (default 60 deg) define the camera."""
+        self.device = torch.device(device)
+        self.conf = conf
+        self.images = None
+        self.masks = None
+        self.poses = None
+        self.images_lis = []
+        data_dir = None if conf is None else conf.get_string("data_dir", default=None)
+        meta = None
+        if data_dir is not None and os.path.exists(os.path.join(data_dir, "transforms_train.json")):
+            with open(os.path.join(data_dir, "transforms_train.json")) as fp:
+                meta = json.load(fp)
+        if meta is not None:
+            poses, imgs = [], []
+            for frame in meta["frames"]:
+                fname = os.path.join(data_dir, frame["file_path"] + ".png")
+                self.images_lis.append(fname)
+                poses.append(np.array(frame["transform_matrix"]))
+                if load_images:
+                    from PIL import Image
+                    imgs.append(np.asarray(Image.open(fname).convert("RGB")))
+            self.poses = torch.from_numpy(np.array(poses).astype(np.float32)).to(self.device)
+            if load_images:
+                images = (np.array(imgs) / 255.0).astype(np.float32)
+                images = images[:, :, ::-1]                       # dataset.py:226 (mirrors the W axis)
+                self.images = torch.from_numpy(images.copy()).cpu()
+                self.masks = torch.zeros_like(self.images)
+                self.masks[self.images != 0] = 1.0                # dataset.py:228-229
+                H0, W0 = self.images[0].shape[:2]
+            else:
+                H0 = W0 = 256
+            camera_angle_x = float(meta["camera_angle_x"])
+        else:
+            H0 = W0 = 256
+        self.n_images = 0 if self.poses is None else len(self.poses)
+        self.H = int(H) if H is not None else H0
+        self.W = int(W) if W is not None else W0
+        if camera_angle_x is None:
+            camera_angle_x = np.pi / 3
+        self.focal = 0.5 * self.W / np.tan(0.5 * camera_angle_x)   # dataset.py:234-235
+        self.image_pixels = self.H * self.W
+        self.object_bbox_min = np.array([-1.01, -1.01, -1.01])
+        self.object_bbox_max = np.array([1.01, 1.01, 1.01])
+        self.K = torch.tensor([[self.focal, 0, 0.5 * self.W], [0, self.focal, 0.5 * self.H], [0, 0, 1]], dtype=torch.float64)
+
+    # ------------------------------------------------------------------ rays
+    def _dirs(self, px, py, pose):
+        p = torch.stack([(px - 0.5 * self.W) / self.focal, -(py - 0.5 * self.H) / self.focal, -torch.ones_like(px)], -1).float()
+        v = p / torch.linalg.norm(p, ord=2, dim=-1, keepdim=True)
+        pose = pose.to(v.device).float()
+        v = torch.sum(v[..., None, :] * pose[:3, :3], -1)
+        o = pose[:3, 3].expand(v.shape)
+        return o, v
+
+    def gen_rays_pose(self, pose, resolution_level=1):
+        """dataset.py:277-293."""
+        l = resolution_level
+        dev = self.device
+        tx = torch.linspace(0, self.W - 1, int(self.W // l), device=dev)
+        ty = torch.linspace(0, self.H - 1, int(self.H // l), device=dev)
+        px, py = torch.meshgrid(tx, ty, indexing="ij")
+        return self._dirs(px.t(), py.t(), torch.as_tensor(pose))
+
+    def gen_rays_at(self, img_idx, resolution_level=1):
+        """dataset.py:295-312."""
+        return self.gen_rays_pose(self.poses[img_idx], resolution_level)
+
+    def gen_random_rays_at(self, img_idx, batch_size):
+        """dataset.py:314-329 -> [B,10] = o, d, rgb, mask."""
+        px = torch.randint(low=0, high=self.W, size=[batch_size])
+        py = torch.randint(low=0, high=self.H, size=[batch_size])
+        color = self.images[img_idx][(py, px)]
+        mask = self.masks[img_idx][(py, px)]
+        o, v = self._dirs(px.to(self.device).float(), py.to(self.device).float(), self.poses[img_idx])
+        return torch.cat([o, v, color.to(self.device), mask[:, :1].to(self.device)], dim=-1)
+
+    def gen_rays_silhouettes(self, pose, max_ray_num, mask):
+        """dataset.py:252-275: rays only inside the 10x-dilated silhouette `mask` [256,256]."""
+        from scipy import ndimage
+        mask_np = mask.detach().cpu().numpy() if torch.is_tensor(mask) else np.asarray(mask)
+        if mask_np.sum() == 0:
+            return self.gen_rays_pose(pose, resolution_level=4)
+        struct = ndimage.generate_binary_structure(2, 2)
+        dilated = ndimage.binary_dilation(mask_np, structure=struct, iterations=10).astype(np.int32)
+        ratio = dilated.sum() / float(mask_np.shape[0] * mask_np.shape[1])
+        Wn = Hn = min(self.H, int(np.sqrt(max_ray_num / ratio)))
+        dev = self.device
+        tx = torch.linspace(0, self.W - 1, Wn, device=dev)
+        ty = torch.linspace(0, self.H - 1, Hn, device=dev)
+        px, py = torch.meshgrid(tx, ty, indexing="ij")
+        o, v = self._dirs(px.t(), py.t(), torch.as_tensor(pose))
+        m = torch.nn.functional.interpolate(torch.from_numpy(dilated).reshape(1, 1, *dilated.shape).float(), size=(Hn, Wn)).squeeze()
+        sel = (m > 0).to(dev)
+        return o[sel], v[sel], Wn, sel
+
+    def near_far_from_sphere(self, rays_o, rays_d, is_sphere=False):
+        """dataset.py:331-342 (`is_sphere` is ignored by the reference too)."""
+        a = torch.sum(rays_d ** 2, dim=-1, keepdim=True)
+        b = 2.0 * torch.sum(rays_o * rays_d, dim=-1, keepdim=True)
+        mid = 0.5 * (-b) / a
+        near = (mid - 1).clamp(min=0)
+        far = mid + 1
+        return near, far
+
+    def image_at(self, idx, resolution_level):
+        from PIL import Image
+        img = np.asarray(Image.open(self.images_lis[idx]).convert("RGB"))[:, ::-1, ::-1]   # BGR + mirror like cv2 path
+        size = (self.W // resolution_level, self.H // resolution_level)
+        return np.asarray(Image.fromarray(np.ascontiguousarray(img)).resize(size, Image.BILINEAR)).clip(0, 255)

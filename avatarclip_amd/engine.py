@@ -70,6 +70,8 @@ def flatten_dense(sdf_net, col_net, spec: PK.NetSpec) -> torch.Tensor:
 
 class Engine:
     _by_net = weakref.WeakKeyDictionary()
+    PROFILE = False               # bench.py: record (name, points, start_event, end_event) per kernel launch group
+    prof_events = []
     MAX_BWD_WAVES = 1024          # 256 CUs x 4 wavefronts (one per SIMD: the backward kernel uses the full RF)
     PANEL_BYTES_BUDGET = 12 << 30  # weight-gradient operand panels per chunk of points
 
@@ -103,6 +105,23 @@ class Engine:
             cls._by_net[sdf_net] = eng
         return eng
 
+    class _Timed:
+        def __init__(self, name, npts):
+            self.name, self.npts = name, npts
+
+        def __enter__(self):
+            if Engine.PROFILE:
+                self.e0 = torch.cuda.Event(enable_timing=True)
+                self.e1 = torch.cuda.Event(enable_timing=True)
+                self.e0.record()
+            return self
+
+        def __exit__(self, *a):
+            if Engine.PROFILE:
+                self.e1.record()
+                Engine.prof_events.append((self.name, self.npts, self.e0, self.e1))
+            return False
+
     # ------------------------------------------------------------------ packing
     def pack(self, flatP: torch.Tensor) -> Packed:
         return Packed(self.dl, flatP)
@@ -120,9 +139,10 @@ class Engine:
         R, S = z.shape
         if sdf_out is None:
             sdf_out = torch.empty(R, S, device=self.device, dtype=torch.float32)
-        L.check(self.lib.avc_sdf_forward(self.net, None, L.ptr(rays_o), L.ptr(rays_d), L.ptr(z), S, z.stride(0), R * S,
-                                         L.ptr(pk.w_f16), L.ptr(pk.tab), self.dl.offsets, L.ptr(sdf_out),
-                                         L.ptr(slot), ld_out, L.stream()), "avc_sdf_forward")
+        with Engine._Timed("avc_sdf_forward", R * S):
+            L.check(self.lib.avc_sdf_forward(self.net, None, L.ptr(rays_o), L.ptr(rays_d), L.ptr(z), S, z.stride(0), R * S,
+                                             L.ptr(pk.w_f16), L.ptr(pk.tab), self.dl.offsets, L.ptr(sdf_out),
+                                             L.ptr(slot), ld_out, L.stream()), "avc_sdf_forward")
         return sdf_out
 
     def sdf_pts(self, pk: Packed, pts):
@@ -150,9 +170,10 @@ class Engine:
         sdf = torch.empty(R, S, device=self.device, dtype=torch.float32)
         nrm = torch.empty(R, S, 3, device=self.device, dtype=torch.float32)
         rgb = torch.empty(R, S, 6, device=self.device, dtype=torch.float32)
-        L.check(self.lib.avc_render_points_fwd(self.net, None, L.ptr(rays_o), L.ptr(rays_d), L.ptr(z), S, z.stride(0),
-                                               float(sample_dist), N, L.ptr(pk.w_f16), L.ptr(pk.tab), self.dl.offsets,
-                                               L.ptr(sdf), L.ptr(nrm), L.ptr(rgb), L.stream()), "avc_render_points_fwd")
+        with Engine._Timed("avc_render_points_fwd", N):
+            L.check(self.lib.avc_render_points_fwd(self.net, None, L.ptr(rays_o), L.ptr(rays_d), L.ptr(z), S, z.stride(0),
+                                                   float(sample_dist), N, L.ptr(pk.w_f16), L.ptr(pk.tab), self.dl.offsets,
+                                                   L.ptr(sdf), L.ptr(nrm), L.ptr(rgb), L.stream()), "avc_render_points_fwd")
         return sdf, nrm, rgb
 
     def composite_fwd(self, sdf, nrm, rgb, z, rays_o, rays_d, inv_s, sample_dist, cos_anneal, bg, bg_mode):
@@ -205,17 +226,19 @@ class Engine:
             r1 = min(R, r0 + rays_per_chunk)
             npts = (r1 - r0) * S
             nblk = (npts + 31) // 32
-            L.check(self.lib.avc_render_points_bwd(
-                self.net, None, rays_o.data_ptr() + r0 * 3 * esz, rays_d.data_ptr() + r0 * 3 * esz,
-                z.data_ptr() + r0 * z.stride(0) * esz, S, z.stride(0), float(sample_dist), npts, L.ptr(pk.w_f16),
-                L.ptr(pk.w_bf16), L.ptr(pk.tab), self.dl.offsets, d_sdf.data_ptr() + r0 * S * esz,
-                d_n.data_ptr() + r0 * S * 3 * esz, d_rgb.data_ptr() + r0 * S * 6 * esz, L.ptr(panels),
-                self.MAX_BWD_WAVES, L.ptr(scratch), st), "avc_render_points_bwd")
+            with Engine._Timed("avc_render_points_bwd", npts):
+                L.check(self.lib.avc_render_points_bwd(
+                    self.net, None, rays_o.data_ptr() + r0 * 3 * esz, rays_d.data_ptr() + r0 * 3 * esz,
+                    z.data_ptr() + r0 * z.stride(0) * esz, S, z.stride(0), float(sample_dist), npts, L.ptr(pk.w_f16),
+                    L.ptr(pk.w_bf16), L.ptr(pk.tab), self.dl.offsets, d_sdf.data_ptr() + r0 * S * esz,
+                    d_n.data_ptr() + r0 * S * 3 * esz, d_rgb.data_ptr() + r0 * S * 6 * esz, L.ptr(panels),
+                    self.MAX_BWD_WAVES, L.ptr(scratch), st), "avc_render_points_bwd")
             nsplit = max(1, min(nblk, 1024 // 8))
-            for (pa, ta, pb, tb, out_off, bias_off) in lay.pairs:
-                bptr = gbias.data_ptr() + bias_off * 4 if bias_off >= 0 else None
-                L.check(self.lib.avc_weight_grad(L.ptr(panels), self.ptiles, pa, ta, pb, tb, nblk,
-                                                 gout.data_ptr() + out_off * 4, bptr, nsplit, st), "avc_weight_grad")
+            with Engine._Timed("avc_weight_grad(all pairs)", npts):
+                for (pa, ta, pb, tb, out_off, bias_off) in lay.pairs:
+                    bptr = gbias.data_ptr() + bias_off * 4 if bias_off >= 0 else None
+                    L.check(self.lib.avc_weight_grad(L.ptr(panels), self.ptiles, pa, ta, pb, tb, nblk,
+                                                     gout.data_ptr() + out_off * 4, bptr, nsplit, st), "avc_weight_grad")
         grad = torch.zeros(lay.nparam, device=self.device, dtype=torch.float32)
         grad.index_add_(0, self.dl.un_tgt, gout[self.dl.un_src] * self.dl.un_scale)
         if lay.gbias_size:

@@ -1,0 +1,231 @@
+"""Benchmark of the AvatarCLIP AppearanceGen hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is ONE full CLIP-guided optimisation iteration of Runner.train_clip (reference: main.py:345-566) on a
+512x512 full-frame view per GPU, 64 samples/ray (32 coarse + 32 importance in 4 up-sampling steps), full-size
+networks (confs/examples/*.conf), two CLIP ViT-B/32 passes (textured + untextured shading), all losses, backward
+(incl. the double backward through the SDF normals), one RCCL gradient all-reduce, Adam.  Data is synthetic:
+seeded geometric-init weights, seeded CLIP weights / text embeddings, procedural silhouette prior, random cameras
+drawn with the reference's sampling code.
+
+Prints ONE JSON line (rank 0).  value = whole-job rays/s (all ranks), weak scaling (one view per GPU per step).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic GEMM FLOPs per sample point, full net (SURVEY.md §8d / BASELINE.md §2)
+F_SDF, F_GRAD, F_COL = 524800, 393728, 268288
+F_PT = F_SDF + F_GRAD + F_COL
+F_SDF_ONLY = 2 * (39 * 256 + 2 * 256 * 256 + 256 * 217 + 256)   # SDF value only (row 0 of the last layer)
+PEAK_MFMA = 2.5e15   # dense bf16/f16 MFMA, MI355X_MICROARCH.md
+
+
+def make_conf(res, spp, small=False):
+    from avatarclip_amd.conf import ConfigFactory
+    H = 128 if small else 256
+    text = """
+general { base_exp_dir = /tmp/avc_bench_exp
+          recording = [] }
+dataset { H = %d
+          W = %d }
+train {
+    learning_rate = 5e-4
+    learning_rate_alpha = 0.05
+    end_iter = 100000
+    batch_size = 512
+    validate_resolution_level = 1
+    warm_up_end = 500
+    anneal_end = 0
+    use_white_bkgd = False
+    save_freq = 100000000
+    val_freq = 100000000
+    val_mesh_freq = 100000000
+    report_freq = 100000000
+    igr_weight = 0.1
+    mask_weight = 1.0
+    clip_weight = 1.0
+    add_no_texture = True
+    texture_cast_light = True
+    use_face_prompt = True
+    use_back_prompt = True
+    use_silhouettes = False
+    full_frame_resolution_level = 1
+}
+clip { prompt = a 3D rendering of the Iron Man in unreal engine }
+model {
+    sdf_network { d_out = %d
+        d_in = 3
+        d_hidden = %d
+        n_layers = %d
+        skip_in = [%d]
+        multires = 6
+        bias = 0.5
+        scale = 1.0
+        geometric_init = True
+        weight_norm = True }
+    variance_network { init_val = 0.3 }
+    rendering_network { d_feature = %d
+        mode = no_view_dir
+        d_in = 6
+        d_out = 3
+        d_hidden = %d
+        n_layers = %d
+        weight_norm = True
+        multires_view = 0
+        squeeze_out = True
+        extra_color = True }
+    neus_renderer { n_samples = %d
+        n_importance = %d
+        n_outside = 0
+        up_sample_steps = 4
+        perturb = 1.0
+        extra_color = True }
+}
+""" % (res, res, H + 1, H, 3 if small else 4, 3 if small else 4, H, H, 1 if small else 2, spp // 2, spp // 2)
+    return ConfigFactory.parse_string(text)
+
+
+def cpu_baseline(spp, rays=1024, iters=2):
+    """The CPU oracle (port of the reference's algorithm, oracle/neus_oracle.py + clip_vit_oracle.py) on a bounded
+    sample of the same workload: `rays` rays of one view, full-size nets, full step incl. 2 CLIP passes and Adam."""
+    from oracle import neus_oracle as O, clip_vit_oracle as C
+    from avatarclip_amd import fields
+    torch.set_num_threads(os.cpu_count() or 1)
+    torch.manual_seed(0)
+    sdf = fields.SDFNetwork(d_out=257, d_in=3, d_hidden=256, n_layers=4, skip_in=[4], multires=6)
+    col = fields.RenderingNetwork(d_feature=256, mode="no_view_dir", d_in=6, d_out=3, d_hidden=256, n_layers=2, extra_color=True)
+    var = torch.nn.Parameter(torch.tensor(0.3))
+    params = list(sdf.parameters()) + list(col.parameters()) + [var]
+    opt = torch.optim.Adam(params, lr=5e-4)
+    clip_sd = C.random_state_dict(0)
+    text = torch.nn.functional.normalize(torch.randn(1, 512, generator=torch.Generator().manual_seed(11)), dim=-1)
+    side = int(round(rays ** 0.5))
+    pose = torch.from_numpy(O.lookat(np.array([0.3, 0.2, 1.5]), np.zeros(3), np.array([0., 1, 0]))).float()
+    o, v = O.gen_rays_pose(pose, side, side, 0.5 * side / np.tan(np.pi / 6))
+    ro, rd = o.reshape(-1, 3).contiguous(), v.reshape(-1, 3).contiguous()
+    near, far = O.near_far_from_sphere(ro, rd)
+    R = ro.shape[0]
+    times = []
+    for it in range(iters + 1):
+        t0 = time.time()
+        sd_s, sd_c = dict(sdf.named_parameters()), dict(col.named_parameters())
+        jitter = torch.rand(R, 1)
+        out = O.render(sd_s, sd_c, var, ro, rd, near, far, spp // 2, spp // 2, 4, jitter, torch.zeros(1, 3), 1.0)
+        tex, shade = O.cast_light(out, np.array([0.3, 0.5, 0.8]), 0.1)
+        loss, _, _, _ = O.neus_losses(out, torch.zeros(R, 3), torch.ones(R, 1), 0.1, 1.0)
+        for img in (tex, shade):
+            enc = C.encode_image(clip_sd, O.clip_preprocess(img.reshape(side, side, 3)))
+            loss = loss + (1.0 - O.clip_cosine(enc, text))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        times.append(time.time() - t0)
+    t = float(np.mean(times[1:]))
+    return {"value": R / t, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d rays (%dx%d view) x %d spp, full nets, full step incl. 2 CLIP passes + Adam, %d timed iters, %.2f s/iter"
+                      % (R, side, side, spp, iters, t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--small", action="store_true", help="128-wide nets (confs/examples_small)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from avatarclip_amd import parallel
+    from avatarclip_amd.engine import Engine
+    from avatarclip_amd.runner import Runner
+    rank, world, local_rank = parallel.init_from_env()
+    assert world == max(args.gpus, 1) or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    torch.manual_seed(0)             # identical initial weights on every rank
+    np.random.seed(1234 + rank)      # a different camera view per rank (view-sharded DP)
+    conf = make_conf(args.res, args.spp, args.small)
+    runner = Runner(None, mode="train_clip", conf=conf, device=dev)
+    runner.init_clip()
+    runner.init_smpl()
+    runner.update_learning_rate()
+
+    def step(i):
+        runner.train_clip_iteration(i)
+        runner.update_learning_rate()
+
+    for i in range(args.warmup):
+        step(i)
+    Engine.PROFILE = True
+    Engine.prof_events = []
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    dt = time.perf_counter() - t0
+    dt = parallel.max_over_ranks(dt, dev)
+    Engine.PROFILE = False
+
+    if rank == 0:
+        rays_per_step = args.res * args.res * world
+        # dominant kernel: mlp_bwd_kernel (avc_render_points_bwd); events recorded on the launch stream
+        per_kernel = {}
+        for name, npts, e0, e1 in Engine.prof_events:
+            per_kernel.setdefault(name, []).append((npts, e0.elapsed_time(e1) * 1e-3))
+        roof = None
+        if "avc_render_points_bwd" in per_kernel and not args.small:
+            recs = per_kernel["avc_render_points_bwd"]
+            avg_t = float(np.mean([t for _, t in recs]))
+            avg_pts = float(np.mean([n for n, _ in recs]))
+            flops = 2.0 * F_PT * avg_pts          # forward recompute + every dX product (incl. double backward)
+            roof = {"kernel": "mlp_bwd_kernel (avc_render_points_bwd)", "bound": "mfma", "achieved": flops / avg_t / 1e12,
+                    "peak": PEAK_MFMA / 1e12, "unit": "TFLOP/s", "frac": flops / avg_t / PEAK_MFMA, "traffic": None,
+                    "avg_launch_ms": avg_t * 1e3, "points_per_launch": avg_pts, "launches": len(recs),
+                    "algorithmic_flop_per_point": 2.0 * F_PT}
+        kern_ms = {k: 1e3 * float(np.sum([t for _, t in v])) / args.steps for k, v in per_kernel.items()}
+        out = {
+            "metric": "rays_per_sec_512x512_64spp_clip_guided_train_iter",
+            "value": rays_per_step * args.steps / dt,
+            "unit": "rays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "iters_per_sec": args.steps / dt,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16 (forward) / bf16 (gradient sweeps) MFMA operands, fp32 accumulate",
+            "data": "synthetic",
+            "config": {"workload": "AppearanceGen train_clip iteration, %dx%d full-frame view per GPU, %d spp (%d+%d, 4 up-sample steps), "
+                                   "%s nets, 2 CLIP ViT-B/32 passes, Adam, %d view(s)/step"
+                                   % (args.res, args.res, args.spp, args.spp // 2, args.spp // 2,
+                                      "small (128-wide)" if args.small else "full-size (256-wide)", world),
+                       "parallelism": "view-sharded dp%d, one flat RCCL all-reduce/step" % world},
+            "kernel_ms_per_step": kern_ms,
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.spp)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    parallel.barrier()
+
+
+if __name__ == "__main__":
+    main()

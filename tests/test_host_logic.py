@@ -1,0 +1,131 @@
+"""CPU tests of the host-side logic: conf parser, ray generation vs the golden vectors, camera helpers,
+fields state-dict compatibility with the reference checkpoint layout, C-ABI symbol export."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import torch
+
+from tests.helpers import load_case, GOLDEN, ROOT
+
+EXAMPLE_CONF = """
+general {
+    base_exp_dir = ./exp/smpl/example
+    recording = [
+        ./,
+        ./models
+    ]
+}
+train {
+    learning_rate = 5e-4
+    end_iter = 30000
+    use_white_bkgd = False
+    warm_up_end = 500
+    mask_weight = 1.0   # trailing comment
+    add_no_texture = True
+}
+clip {
+    prompt = a 3D rendering of a {TOREPLACE} in unreal engine
+}
+model {
+    nerf {
+        D = 4,
+        skips=[4],
+        use_viewdirs=True
+    }
+    sdf_network {
+        d_out = 129
+        skip_in = [3]
+        scale = 1.0
+    }
+    neus_renderer {
+        up_sample_steps = 4     # 1 for simple coarse-to-fine sampling
+        perturb = 1.0
+    }
+}
+"""
+
+
+def test_conf_parser_subset():
+    from avatarclip_amd.conf import ConfigFactory
+    c = ConfigFactory.parse_string(EXAMPLE_CONF)
+    assert c["general.base_exp_dir"] == "./exp/smpl/example"
+    assert c["general.recording"] == ["./", "./models"]
+    assert c.get_float("train.learning_rate") == 5e-4 and c.get_int("train.end_iter") == 30000
+    assert c.get_bool("train.use_white_bkgd") is False and c.get_bool("train.add_no_texture") is True
+    assert c.get_float("train.mask_weight") == 1.0
+    assert c.get_string("clip.prompt") == "a 3D rendering of a {TOREPLACE} in unreal engine"
+    assert c["model.nerf.D"] == 4 and c["model.nerf.skips"] == [4] and c["model.nerf.use_viewdirs"] is True
+    assert dict(c["model.sdf_network"]) == {"d_out": 129, "skip_in": [3], "scale": 1.0}
+    assert c["model.neus_renderer.up_sample_steps"] == 4
+    assert c.get_float("train.anneal_end", default=0.0) == 0.0
+    try:
+        c.get_float("train.clip_weight")
+        assert False
+    except KeyError:
+        pass
+
+
+def test_rays_match_reference_golden():
+    from avatarclip_amd.dataset import SMPL_Dataset
+    from avatarclip_amd import utils as U
+    z = np.load(os.path.join(GOLDEN, "rays_cam.npz"))
+    ds = SMPL_Dataset(None, device="cpu", H=256, W=256)
+    assert abs(ds.focal - float(z["focal"])) < 1e-9
+    pose = torch.from_numpy(z["pose58"])
+    for lvl in (4, 2.25):
+        o, v = ds.gen_rays_pose(pose, lvl)
+        assert np.allclose(o.numpy(), z["rays_o_l%s" % lvl], atol=1e-6) and np.allclose(v.numpy(), z["rays_v_l%s" % lvl], atol=1e-6)
+    o, v = ds.gen_rays_pose(pose, 4)
+    near, far = ds.near_far_from_sphere(o.reshape(-1, 3), v.reshape(-1, 3))
+    assert np.allclose(near.numpy(), z["near_l4"], atol=1e-6) and np.allclose(far.numpy(), z["far_l4"], atol=1e-6)
+    np.random.seed(0)
+    for k in range(8):
+        eye, theta, phi, is_front = U.random_eye_normal()
+        at = U.random_at().astype(np.float32)
+        eye = eye.astype(np.float32) + at
+        assert np.allclose(eye, z["cam_eye"][k]) and np.allclose(at, z["cam_at"][k])
+        assert np.allclose(U.lookat(eye, at, np.array([0, 1, 0])), z["cam_pose"][k], atol=1e-6)
+        assert np.allclose([theta, phi, is_front], z["cam_aux"][k])
+    for i in range(6):
+        assert np.allclose(U.sphere_coord(0.3 * i, 0.7 * i), z["sphere_coord"][i])
+
+
+def test_fields_state_dict_compat_and_torch_forward():
+    """Reference checkpoint keys load unmodified; the API-compat torch forward equals the oracle."""
+    from avatarclip_amd import fields
+    from oracle import neus_oracle as O
+    rec, sd_sdf, sd_col, variance = load_case("neus_small.npz")
+    sdf = fields.SDFNetwork(d_out=129, d_in=3, d_hidden=128, n_layers=3, skip_in=[3], multires=6, bias=0.5, scale=1.0,
+                            geometric_init=True, weight_norm=True)
+    col = fields.RenderingNetwork(d_feature=128, mode="no_view_dir", d_in=6, d_out=3, d_hidden=128, n_layers=1,
+                                  weight_norm=True, multires_view=0, squeeze_out=True, extra_color=True)
+    assert set(sdf.state_dict().keys()) == set(sd_sdf.keys())
+    assert set(col.state_dict().keys()) == set(sd_col.keys())
+    sdf.load_state_dict(sd_sdf)
+    col.load_state_dict(sd_col)
+    x = torch.rand(64, 3) - 0.5
+    assert torch.allclose(sdf(x), O.sdf_forward(sd_sdf, x), atol=1e-6)
+    n = torch.randn(64, 3)
+    feat = torch.randn(64, 128)
+    assert torch.allclose(col(x, n, None, feat), O.color_forward(sd_col, x, n, feat), atol=1e-6)
+    # dense flattening order == packing.param_shapes
+    from avatarclip_amd import packing as PK
+    from avatarclip_amd.engine import flatten_dense
+    flat = flatten_dense(sdf, col, PK.SMALL)
+    assert flat.numel() == PK.layout_for(PK.SMALL).nparam
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from avatarclip_amd import build
+    path = build.build()
+    lib = ctypes.CDLL(path)
+    hdr = open(os.path.join(ROOT, "include", "avc.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = re.findall(r"\b(avc_\w+)\s*\(", hdr)
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), n
+    lib.avc_version.restype = ctypes.c_int
+    assert lib.avc_version() >= 1

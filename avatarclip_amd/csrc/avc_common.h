@@ -109,11 +109,18 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf
 template <typename V> __device__ __forceinline__ void set8(V& f, int j, float v) { f[j] = (typename MF<V>::S)v; }
 template <typename V> __device__ __forceinline__ float get8(const V& f, int j) { return (float)f[j]; }
 
+// Pin freshly produced fragments at this program point: LLVM otherwise SINKS the whole (pure) epilogue of a tile down to
+// its first use in the next layer, keeping every fp32 accumulator of the layer alive (hundreds of spilled VGPRs).
+template <typename V>
+__device__ __forceinline__ void pin2(V& f0, V& f1) {
+  asm volatile("" : "+v"(f0), "+v"(f1));
+}
 // accumulator tile (already activated, fp32) -> the two B-operand k-steps it feeds
 template <typename V>
 __device__ __forceinline__ void acc_to_frags(const float (&a)[16], V& f0, V& f1) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) { set8(f0, j, a[j]); set8(f1, j, a[8 + j]); }
+  pin2(f0, f1);
 }
 
 __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32); }

@@ -3,6 +3,7 @@
 // (RenderingNetwork.forward, mode 'no_view_dir', extra_color) of the reference.
 #pragma once
 #include "avc_common.h"
+#include "avc_stage.h"
 
 template <int H_, int NMID_, int NCMID_>
 struct NetT {
@@ -51,22 +52,46 @@ __device__ __forceinline__ const V* tptr(const V* blob, int off, int t, int lane
   return blob + (off >> 3) + (long)(t * KS) * 64 + lane;
 }
 
-// out = act(W in + b) for an H-wide (NT tiles) layer; ACT 0 none, 1 softplus(beta=100), 2 relu
-template <typename V, int KS, int NT, int ACT>
-__device__ __forceinline__ void dense_layer(const V* __restrict__ blob, int offw, const float* __restrict__ bias,
-                                            int lane, int h, const V (&in)[KS], V (&out)[2 * NT]) {
-  float b[16], a[16];
+
+// ---- staged, software-pipelined layer: tile t's MFMAs are issued before the epilogue of tile t-1, so the VALU /
+// ---- transcendental work of one tile hides under the matrix pipe of the next (same basic block, no barrier between).
+#define AVC_EPI(...) [&](int t, const facc& acc) __attribute__((always_inline)) { __VA_ARGS__ }
+
+template <typename V, int KS, int NT, int KSN, typename Epi>
+__device__ __forceinline__ void layer_s(Stage& st, const V* __restrict__ blob, int offw, const void* __restrict__ gnext_after,
+                                        const V (&in)[KS], Epi&& epi) {
+  facc prev;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    facc acc = tile_gemm<V, KS>(tptr<V, KS>(blob, offw, t, lane), in);
-    load16(bias, t, h, b);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float v = acc[r] + b[r];
-      a[r] = ACT == 1 ? softplus100(v) : (ACT == 2 ? fmaxf(v, 0.f) : v);
-    }
-    acc_to_frags(a, out[2 * t], out[2 * t + 1]);
+    facc acc = (t + 1 < NT) ? tile_gemm_s<V, KS, KS>(st, gtile<V, KS>(blob, offw, t + 1), in)
+                            : tile_gemm_s<V, KS, KSN>(st, gnext_after, in);
+#ifdef AVC_NO_PIPE
+    epi(t, acc);
+#else
+    if (t > 0) epi(t - 1, prev);
+    prev = acc;
+#endif
+    __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from sinking epilogues past later tiles (spills)
   }
+#ifndef AVC_NO_PIPE
+  epi(NT - 1, prev);
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+template <typename V, int KA, int KB, int NT, int KSN, typename Epi>
+__device__ __forceinline__ void layer2_s(Stage& st, const V* __restrict__ blob, int offw, const void* __restrict__ gnext_after,
+                                         const V (&ina)[KA], const V (&inb)[KB], Epi&& epi) {
+  facc prev;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    facc acc = (t + 1 < NT) ? tile_gemm2_s<V, KA, KB, KA + KB>(st, gtile<V, KA + KB>(blob, offw, t + 1), ina, inb)
+                            : tile_gemm2_s<V, KA, KB, KSN>(st, gnext_after, ina, inb);
+    if (t > 0) epi(t - 1, prev);
+    prev = acc;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  epi(NT - 1, prev);
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 // Forward state of one wave (kept in registers for the reverse sweeps).
@@ -82,29 +107,48 @@ struct FwdState {
 };
 
 // SDF trunk: layer0 .. skip layer, plus the fp32 sdf dot product (row 0 of the last layer).
-template <class N>
-__device__ __forceinline__ void sdf_trunk(const h8* __restrict__ Wf, const float* __restrict__ T, const AvcOffsets& o,
-                                          int lane, int h, FwdState<N>& st) {
+// Precondition: tile 0 of OFF_W0 has been issued (stage_issue).  gnext/KSN: the tile consumed after the trunk.
+template <class N, int KSN>
+__device__ __forceinline__ void sdf_trunk(Stage& sg, const h8* __restrict__ Wf, const float* __restrict__ T, const AvcOffsets& o,
+                                          int h, FwdState<N>& st, const void* __restrict__ gnext) {
   pe_compute(st.x, h, st.pe);
   pe_to_frags_f16(st.pe, st.x, h, st.pef);
-  float b[16], a[16];
-  dense_layer<h8, 3, N::HT, 1>(Wf, o.v[OFF_W0], T + o.v[OFF_B0], lane, h, st.pef, st.h1);
-  dense_layer<h8, N::HK, N::HT, 1>(Wf, o.v[OFF_WM0], T + o.v[OFF_BM0], lane, h, st.h1, st.hm[0]);
-  if constexpr (N::NMID == 2)
-    dense_layer<h8, N::HK, N::HT, 1>(Wf, o.v[OFF_WM1], T + o.v[OFF_BM1], lane, h, st.hm[0], st.hm[1]);
-  // skip layer H -> SKIP, with the fp32 sdf dot product folded into its epilogue
-  float part = 0.f;
-#pragma unroll
-  for (int t = 0; t < N::ST; ++t) {
-    facc acc = tile_gemm<h8, N::HK>(tptr<h8, N::HK>(Wf, o.v[OFF_WS], t, lane), st.hm[N::NMID - 1]);
-    load16(T + o.v[OFF_BS], t, h, b);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
-    load16(T + o.v[OFF_WL0_ACC], t, h, b);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) part += b[r] * a[r];
-    acc_to_frags(a, st.hs[2 * t], st.hs[2 * t + 1]);
+  layer_s<h8, 3, N::HT, N::HK>(sg, Wf, o.v[OFF_W0], gtile<h8, N::HK>(Wf, o.v[OFF_WM0], 0), st.pef, AVC_EPI(
+    float b[16], a[16];
+    load16(T + o.v[OFF_B0], t, h, b);
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
+    acc_to_frags(a, st.h1[2 * t], st.h1[2 * t + 1]);
+  ));
+  if constexpr (N::NMID == 2) {
+    layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM0], gtile<h8, N::HK>(Wf, o.v[OFF_WM1], 0), st.h1, AVC_EPI(
+      float b[16], a[16];
+      load16(T + o.v[OFF_BM0], t, h, b);
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
+      acc_to_frags(a, st.hm[0][2 * t], st.hm[0][2 * t + 1]);
+    ));
+    layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM1], gtile<h8, N::HK>(Wf, o.v[OFF_WS], 0), st.hm[0], AVC_EPI(
+      float b[16], a[16];
+      load16(T + o.v[OFF_BM1], t, h, b);
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
+      acc_to_frags(a, st.hm[1][2 * t], st.hm[1][2 * t + 1]);
+    ));
+  } else {
+    layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM0], gtile<h8, N::HK>(Wf, o.v[OFF_WS], 0), st.h1, AVC_EPI(
+      float b[16], a[16];
+      load16(T + o.v[OFF_BM0], t, h, b);
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
+      acc_to_frags(a, st.hm[0][2 * t], st.hm[0][2 * t + 1]);
+    ));
   }
+  float part = 0.f;
+  layer_s<h8, N::HK, N::ST, KSN>(sg, Wf, o.v[OFF_WS], gnext, st.hm[N::NMID - 1], AVC_EPI(
+    float b[16], a[16];
+    load16(T + o.v[OFF_BS], t, h, b);
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
+    load16(T + o.v[OFF_WL0_ACC], t, h, b);
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) part += b[r] * a[r];
+    acc_to_frags(a, st.hs[2 * t], st.hs[2 * t + 1]);
+  ));
   {
     const float* wpe = T + o.v[OFF_WL0_PE] + h * 24;
 #pragma unroll
@@ -113,33 +157,80 @@ __device__ __forceinline__ void sdf_trunk(const h8* __restrict__ Wf, const float
   st.sdf = xhalf_sum(part) + T[o.v[OFF_BL0]];
 }
 
-// feature = rows 1..H of the last layer (u = [h_skip ; pe]/sqrt2 folded into the packed weights)
+// SDF value only (avc_sdf_forward): same layers as sdf_trunk but every activation array dies as soon as the next layer
+// has consumed it, which keeps the kernel at two wavefronts per SIMD.
 template <class N>
-__device__ __forceinline__ void sdf_feature(const h8* __restrict__ Wf, const float* __restrict__ T, const AvcOffsets& o,
-                                            int lane, int h, const FwdState<N>& st, h8 (&feat)[N::HK]) {
-  float b[16], a[16];
+__device__ __forceinline__ float sdf_only(Stage& sg, const h8* __restrict__ Wf, const float* __restrict__ T, const AvcOffsets& o,
+                                          int h, const float (&x)[3]) {
+  PE pe;
+  pe_compute(x, h, pe);
+  float part = 0.f;
+  {
+    const float* wpe = T + o.v[OFF_WL0_PE] + h * 24;
 #pragma unroll
-  for (int t = 0; t < N::HT; ++t) {
-    facc acc = tile_gemm2<h8, N::SK, 3>(tptr<h8, N::SK + 3>(Wf, o.v[OFF_WL], t, lane), st.hs, st.pef);
-    load16(T + o.v[OFF_BL], t, h, b);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = acc[r] + b[r];
-    acc_to_frags(a, feat[2 * t], feat[2 * t + 1]);
+    for (int q = 0; q < 24; ++q) part += wpe[q] * pe.v[q];
   }
+  h8 hlast[N::HK];
+  {
+    h8 h1[N::HK];
+    {
+      h8 pef[3];
+      pe_to_frags_f16(pe, x, h, pef);
+      layer_s<h8, 3, N::HT, N::HK>(sg, Wf, o.v[OFF_W0], gtile<h8, N::HK>(Wf, o.v[OFF_WM0], 0), pef, AVC_EPI(
+        float b[16], a[16];
+        load16(T + o.v[OFF_B0], t, h, b);
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
+        acc_to_frags(a, h1[2 * t], h1[2 * t + 1]);
+      ));
+    }
+    if constexpr (N::NMID == 2) {
+      h8 hm0[N::HK];
+      layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM0], gtile<h8, N::HK>(Wf, o.v[OFF_WM1], 0), h1, AVC_EPI(
+        float b[16], a[16];
+        load16(T + o.v[OFF_BM0], t, h, b);
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
+        acc_to_frags(a, hm0[2 * t], hm0[2 * t + 1]);
+      ));
+      layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM1], gtile<h8, N::HK>(Wf, o.v[OFF_WS], 0), hm0, AVC_EPI(
+        float b[16], a[16];
+        load16(T + o.v[OFF_BM1], t, h, b);
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
+        acc_to_frags(a, hlast[2 * t], hlast[2 * t + 1]);
+      ));
+    } else {
+      layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM0], gtile<h8, N::HK>(Wf, o.v[OFF_WS], 0), h1, AVC_EPI(
+        float b[16], a[16];
+        load16(T + o.v[OFF_BM0], t, h, b);
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
+        acc_to_frags(a, hlast[2 * t], hlast[2 * t + 1]);
+      ));
+    }
+  }
+  layer_s<h8, N::HK, N::ST, 1>(sg, Wf, o.v[OFF_WS], (const h8*)nullptr, hlast, AVC_EPI(
+    float b[16], w[16];
+    load16(T + o.v[OFF_BS], t, h, b);
+    load16(T + o.v[OFF_WL0_ACC], t, h, w);
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) part += w[r] * softplus100(acc[r] + b[r]);
+  ));
+  return xhalf_sum(part) + T[o.v[OFF_BL0]];
 }
 
-// Normal n = d sdf / d x by the reverse sweep.  When G != nullptr-like (KEEP), the per-layer
-// g_h (gradient wrt the post-activation h_l) are also returned for the double-backward.
-template <class N, typename V, bool KEEP>
-struct NormalSweep {
-  V ga_s[N::SK];               // g_a of the skip layer output
-  V ga_m[N::NMID][N::HK];      // g_a of middle layer outputs (index m -> layer m+1's output h_{m+2})
-  V ga_1[N::HK];               // g_a of layer0's output
-};
+// feature = rows 1..H of the last layer (u = [h_skip ; pe]/sqrt2 folded into the packed weights)
+template <class N, int KSN>
+__device__ __forceinline__ void sdf_feature(Stage& sg, const h8* __restrict__ Wf, const float* __restrict__ T, const AvcOffsets& o,
+                                            int h, const FwdState<N>& st, h8 (&feat)[N::HK], const void* __restrict__ gnext) {
+  layer2_s<h8, N::SK, 3, N::HT, KSN>(sg, Wf, o.v[OFF_WL], gnext, st.hs, st.pef, AVC_EPI(
+    float b[16], a[16];
+    load16(T + o.v[OFF_BL], t, h, b);
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = acc[r] + b[r];
+    acc_to_frags(a, feat[2 * t], feat[2 * t + 1]);
+  ));
+}
 
-template <class N>
-__device__ __forceinline__ void sdf_normal(const h8* __restrict__ Wf, const float* __restrict__ T, const AvcOffsets& o,
-                                           int lane, int h, const FwdState<N>& st, float (&n)[3]) {
+// Normal n = d sdf / d x by the reverse sweep.
+template <class N, int KSN>
+__device__ __forceinline__ void sdf_normal(Stage& sg, const h8* __restrict__ Wf, const float* __restrict__ T, const AvcOffsets& o,
+                                           int h, const FwdState<N>& st, float (&n)[3], const void* __restrict__ gnext) {
   float w8[8];
   h8 g_in_s[N::SK];
 #pragma unroll
@@ -149,56 +240,58 @@ __device__ __forceinline__ void sdf_normal(const h8* __restrict__ Wf, const floa
     for (int j = 0; j < 8; ++j) g_in_s[s][j] = (_Float16)(w8[j] * sig_from_h((float)st.hs[s][j]));
   }
   h8 g[N::HK];
-  // through the skip layer (transposed): rows = H features of h_{last middle}
-#pragma unroll
-  for (int t = 0; t < N::HT; ++t) {
-    facc acc = tile_gemm<h8, N::SK>(tptr<h8, N::SK>(Wf, o.v[OFF_WST], t, lane), g_in_s);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
+  layer_s<h8, N::SK, N::HT, N::HK>(sg, Wf, o.v[OFF_WST], gtile<h8, N::HK>(Wf, N::NMID == 2 ? o.v[OFF_WM1T] : o.v[OFF_WM0T], 0),
+                                   g_in_s, AVC_EPI(
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {
       g[2 * t][j] = (_Float16)(acc[j] * sig_from_h((float)st.hm[N::NMID - 1][2 * t][j]));
       g[2 * t + 1][j] = (_Float16)(acc[8 + j] * sig_from_h((float)st.hm[N::NMID - 1][2 * t + 1][j]));
     }
-  }
-  // through the middle layers in reverse
-#pragma unroll
-  for (int m = N::NMID - 1; m >= 0; --m) {
-    const int offw = (m == 0) ? o.v[OFF_WM0T] : o.v[OFF_WM1T];
-    h8 g2[N::HK];
-#pragma unroll
-    for (int t = 0; t < N::HT; ++t) {
-      facc acc = tile_gemm<h8, N::HK>(tptr<h8, N::HK>(Wf, offw, t, lane), g);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float s0 = (m == 0) ? (float)st.h1[2 * t][j] : (float)st.hm[m > 0 ? m - 1 : 0][2 * t][j];
-        const float s1 = (m == 0) ? (float)st.h1[2 * t + 1][j] : (float)st.hm[m > 0 ? m - 1 : 0][2 * t + 1][j];
-        g2[2 * t][j] = (_Float16)(acc[j] * sig_from_h(s0));
-        g2[2 * t + 1][j] = (_Float16)(acc[8 + j] * sig_from_h(s1));
+    pin2(g[2 * t], g[2 * t + 1]);
+  ));
+  h8 g2[N::HK];
+  if constexpr (N::NMID == 2) {
+    layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM1T], gtile<h8, N::HK>(Wf, o.v[OFF_WM0T], 0), g, AVC_EPI(
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {
+        g2[2 * t][j] = (_Float16)(acc[j] * sig_from_h((float)st.hm[0][2 * t][j]));
+        g2[2 * t + 1][j] = (_Float16)(acc[8 + j] * sig_from_h((float)st.hm[0][2 * t + 1][j]));
       }
-    }
+      pin2(g2[2 * t], g2[2 * t + 1]);
+    ));
+    layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM0T], gtile<h8, N::HK>(Wf, o.v[OFF_W0T], 0), g2, AVC_EPI(
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {
+        g[2 * t][j] = (_Float16)(acc[j] * sig_from_h((float)st.h1[2 * t][j]));
+        g[2 * t + 1][j] = (_Float16)(acc[8 + j] * sig_from_h((float)st.h1[2 * t + 1][j]));
+      }
+      pin2(g[2 * t], g[2 * t + 1]);
+    ));
+  } else {
+    layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM0T], gtile<h8, N::HK>(Wf, o.v[OFF_W0T], 0), g, AVC_EPI(
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {
+        g2[2 * t][j] = (_Float16)(acc[j] * sig_from_h((float)st.h1[2 * t][j]));
+        g2[2 * t + 1][j] = (_Float16)(acc[8 + j] * sig_from_h((float)st.h1[2 * t + 1][j]));
+      }
+      pin2(g2[2 * t], g2[2 * t + 1]);
+    ));
 #pragma unroll
     for (int s = 0; s < N::HK; ++s) g[s] = g2[s];
   }
-  // through layer 0 (transposed): rows = pe slots, two tiles of 16 slots per half
   float part[3] = {0.f, 0.f, 0.f};
   const float* wpe = T + o.v[OFF_WL0_PE] + h * 24;
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    facc acc = tile_gemm<h8, N::HK>(tptr<h8, N::HK>(Wf, o.v[OFF_W0T], t, lane), g);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
+  layer_s<h8, N::HK, 2, KSN>(sg, Wf, o.v[OFF_W0T], gnext, g, AVC_EPI(
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {
       const int q = 16 * t + r;
       if (q < 24) part[q % 3] += st.pe.d[q] * (acc[r] + wpe[q]);
     }
-  }
+  ));
 #pragma unroll
   for (int c = 0; c < 3; ++c) n[c] = xhalf_sum(part[c]);
 }
 
 // colour MLP: r0 = [x, n, feature] -> ... -> sigmoid([rgb_prior ; rgb_clip])  (6 outputs: half 0 holds 0..3, half 1 holds 4,5)
 template <class N>
-__device__ __forceinline__ void color_forward(const h8* __restrict__ Wf, const float* __restrict__ T, const AvcOffsets& o,
-                                              int lane, int h, const float (&x)[3], const float (&n)[3],
-                                              const h8 (&feat)[N::HK], float (&rgb)[4]) {
+__device__ __forceinline__ void color_forward(Stage& sg, const h8* __restrict__ Wf, const float* __restrict__ T, const AvcOffsets& o,
+                                              int h, const float (&x)[3], const float (&n)[3], const h8 (&feat)[N::HK],
+                                              float (&rgb)[4]) {
   h8 xn[1];
 #pragma unroll
   for (int j = 0; j < 8; ++j) xn[0][j] = (_Float16)0.f;
@@ -206,32 +299,29 @@ __device__ __forceinline__ void color_forward(const h8* __restrict__ Wf, const f
 #pragma unroll
     for (int c = 0; c < 3; ++c) { xn[0][c] = (_Float16)x[c]; xn[0][3 + c] = (_Float16)n[c]; }
   }
-  float b[16], a[16];
   h8 r1[N::HK];
-#pragma unroll
-  for (int t = 0; t < N::HT; ++t) {
-    facc acc = tile_gemm2<h8, N::HK, 1>(tptr<h8, N::HK + 1>(Wf, o.v[OFF_C0], t, lane), feat, xn);
+  layer2_s<h8, N::HK, 1, N::HT, N::HK>(sg, Wf, o.v[OFF_C0], gtile<h8, N::HK>(Wf, N::NCMID == 1 ? o.v[OFF_CM0] : o.v[OFF_CH], 0),
+                                       feat, xn, AVC_EPI(
+    float b[16], a[16];
     load16(T + o.v[OFF_CB0], t, h, b);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r] + b[r], 0.f);
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r] + b[r], 0.f);
     acc_to_frags(a, r1[2 * t], r1[2 * t + 1]);
-  }
-#pragma unroll
-  for (int m = 0; m < N::NCMID; ++m) {
-    h8 r2[N::HK];
-#pragma unroll
-    for (int t = 0; t < N::HT; ++t) {
-      facc acc = tile_gemm<h8, N::HK>(tptr<h8, N::HK>(Wf, o.v[OFF_CM0], t, lane), r1);
+  ));
+  h8 r2[N::HK];
+  if constexpr (N::NCMID == 1) {
+    layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_CM0], gtile<h8, N::HK>(Wf, o.v[OFF_CH], 0), r1, AVC_EPI(
+      float b[16], a[16];
       load16(T + o.v[OFF_CBM0], t, h, b);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r] + b[r], 0.f);
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r] + b[r], 0.f);
       acc_to_frags(a, r2[2 * t], r2[2 * t + 1]);
-    }
+    ));
+  } else {
 #pragma unroll
-    for (int s = 0; s < N::HK; ++s) r1[s] = r2[s];
+    for (int s = 0; s < N::HK; ++s) r2[s] = r1[s];
   }
-  facc acc = tile_gemm<h8, N::HK>(tptr<h8, N::HK>(Wf, o.v[OFF_CH], 0, lane), r1);
-  load16(T + o.v[OFF_CBH], 0, h, b);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) rgb[r] = sigmoidf_(acc[r] + b[r]);
+  layer_s<h8, N::HK, 1, 1>(sg, Wf, o.v[OFF_CH], (const h8*)nullptr, r2, AVC_EPI(
+    float b[16];
+    load16(T + o.v[OFF_CBH], 0, h, b);
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) rgb[r] = sigmoidf_(acc[r] + b[r]);
+  ));
 }

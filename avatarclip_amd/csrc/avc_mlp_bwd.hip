@@ -111,93 +111,25 @@ __device__ __forceinline__ V zero_frag() {
 template <typename V> __device__ __forceinline__ void scr_store(V* scr, int ks, int lane, const V& v) { scr[ks * 64 + lane] = v; }
 template <typename V> __device__ __forceinline__ V scr_load(const V* scr, int ks, int lane) { return scr[ks * 64 + lane]; }
 
-// f16 forward layer that also parks its output in scratch and in a panel
-template <class N, int KS, int NT>
-__device__ __forceinline__ void fwd_layer_keep(const h8* __restrict__ Wf, int offw, const float* __restrict__ bias, int lane,
-                                               int h, const h8 (&in)[KS], h8 (&out)[2 * NT], h8* scr, int scr_ks,
-                                               b8* panel_blk, int ptile, const h8& e0, const h8& e1) {
-  float b[16], a[16];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    facc acc = tile_gemm<h8, KS>(tptr<h8, KS>(Wf, offw, t, lane), in);
-    load16(bias, t, h, b);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
-    acc_to_frags(a, out[2 * t], out[2 * t + 1]);
-    scr_store(scr, scr_ks + 2 * t, lane, out[2 * t]);
-    scr_store(scr, scr_ks + 2 * t + 1, lane, out[2 * t + 1]);
-    panel_store<h8>(panel_blk, ptile + t, lane, out[2 * t], out[2 * t + 1], e0, e1);
-  }
-}
+// All phases run on the staged engine (avc_stage.h / layer_s): every weight tile is copied once per workgroup into
+// LDS, the epilogue of tile t-1 (activation, panel transposition, scratch parking) is issued under the MFMAs of tile t.
+// `live` = this wavefront owns a real 32-point block (waves past the end still walk the tile sequence for the barriers).
 
-// one step of the normal sweep: g_h(prev) = W^T g_a(cur); then g_a(prev) = g_h ⊙ σ(h_prev), q = g_h ⊙ sp''(h_prev)
-template <class N, int KS, int NT>
-__device__ __forceinline__ void normal_step(const h8* __restrict__ Wf, int offw, int lane, const h8 (&gin)[KS],
-                                            h8 (&gout)[2 * NT], h8* scr, int scr_h, int scr_q, b8* panel_blk, int ptile_ga,
-                                            const h8& e0, const h8& e1) {
+template <typename V>
+__device__ __forceinline__ void pstore(b8* __restrict__ panel_blk, bool live, int tile, int lane, const V& f0, const V& f1,
+                                       const V& e0, const V& e1) {
+  facc acc;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    facc acc = tile_gemm<h8, KS>(tptr<h8, KS>(Wf, offw, t, lane), gin);
-    const h8 hv0 = scr_load(scr, scr_h + 2 * t, lane), hv1 = scr_load(scr, scr_h + 2 * t + 1, lane);
-    h8 q0, q1;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  acc = MF<V>::mma(f0, e0, acc);
+  acc = MF<V>::mma(f1, e1, acc);
+  b8 k0, k1;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float s0 = sig_from_h((float)hv0[j]), s1 = sig_from_h((float)hv1[j]);
-      gout[2 * t][j] = (_Float16)(acc[j] * s0);
-      gout[2 * t + 1][j] = (_Float16)(acc[8 + j] * s1);
-      q0[j] = (_Float16)(acc[j] * AVC_BETA * s0 * (1.f - s0) * (1.f / 64.f));   // scaled: keeps beta*g in f16 range
-      q1[j] = (_Float16)(acc[8 + j] * AVC_BETA * s1 * (1.f - s1) * (1.f / 64.f));
-    }
-    scr_store(scr, scr_q + 2 * t, lane, q0);
-    scr_store(scr, scr_q + 2 * t + 1, lane, q1);
-    panel_store<h8>(panel_blk, ptile_ga + t, lane, gout[2 * t], gout[2 * t + 1], e0, e1);
-  }
-}
-
-// one layer of the second-order sweep (i): gbar_a = W gbar_h(in); abar' = gbar_a ⊙ q ; gbar_h(out) = gbar_a ⊙ σ(h_out)
-template <class N, int KS, int NT, bool KEEP_AP_REGS>
-__device__ __forceinline__ void second_step(const b8* __restrict__ Wb, int offw, int lane, const b8 (&gin)[KS],
-                                            b8 (&gout)[2 * NT], h8* scr, int scr_h, int scr_q, int scr_ap, b8 (&ap)[2 * NT],
-                                            b8* panel_blk, int ptile_gbh, const b8& e0, const b8& e1) {
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    facc acc = tile_gemm<b8, KS>(tptr<b8, KS>(Wb, offw, t, lane), gin);
-    const h8 hv0 = scr_load(scr, scr_h + 2 * t, lane), hv1 = scr_load(scr, scr_h + 2 * t + 1, lane);
-    const h8 q0 = scr_load(scr, scr_q + 2 * t, lane), q1 = scr_load(scr, scr_q + 2 * t + 1, lane);
-    b8 a0, a1;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      gout[2 * t][j] = (__bf16)(acc[j] * sig_from_h((float)hv0[j]));
-      gout[2 * t + 1][j] = (__bf16)(acc[8 + j] * sig_from_h((float)hv1[j]));
-      a0[j] = (__bf16)(acc[j] * (float)q0[j] * 64.f);
-      a1[j] = (__bf16)(acc[8 + j] * (float)q1[j] * 64.f);
-    }
-    if (KEEP_AP_REGS) { ap[2 * t] = a0; ap[2 * t + 1] = a1; }
-    else {
-      scr_store(reinterpret_cast<b8*>(scr), scr_ap + 2 * t, lane, a0);
-      scr_store(reinterpret_cast<b8*>(scr), scr_ap + 2 * t + 1, lane, a1);
-    }
-    panel_store<b8>(panel_blk, ptile_gbh + t, lane, gout[2 * t], gout[2 * t + 1], e0, e1);
-  }
-}
-
-// one step of the reverse sweep (ii): hbar(prev) = W^T abar(cur); abar(prev) = abar'(prev) + hbar ⊙ σ(h_prev)
-template <class N, int KS, int NT>
-__device__ __forceinline__ void reverse_step(const b8* __restrict__ Wb, int offw, int lane, const b8 (&ain)[KS],
-                                             b8 (&aout)[2 * NT], h8* scr, int scr_h, int scr_ap, b8* panel_blk, int ptile_ab,
-                                             const b8& e0, const b8& e1) {
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    facc acc = tile_gemm<b8, KS>(tptr<b8, KS>(Wb, offw, t, lane), ain);
-    const h8 hv0 = scr_load(scr, scr_h + 2 * t, lane), hv1 = scr_load(scr, scr_h + 2 * t + 1, lane);
-    const b8 p0 = scr_load(reinterpret_cast<const b8*>(scr), scr_ap + 2 * t, lane);
-    const b8 p1 = scr_load(reinterpret_cast<const b8*>(scr), scr_ap + 2 * t + 1, lane);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      aout[2 * t][j] = (__bf16)((float)p0[j] + acc[j] * sig_from_h((float)hv0[j]));
-      aout[2 * t + 1][j] = (__bf16)((float)p1[j] + acc[8 + j] * sig_from_h((float)hv1[j]));
-    }
-    panel_store<b8>(panel_blk, ptile_ab + t, lane, aout[2 * t], aout[2 * t + 1], e0, e1);
+  for (int j = 0; j < 8; ++j) { k0[j] = (__bf16)acc[j]; k1[j] = (__bf16)acc[8 + j]; }
+  if (live) {
+    b8* dst = panel_blk + (long)tile * 128 + lane;
+    dst[0] = k0;
+    dst[64] = k1;
   }
 }
 
@@ -208,21 +140,27 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PointSrc ps, long npts, co
                                                       const float* __restrict__ d_rgb, b8* __restrict__ panels,
                                                       char* __restrict__ scratch) {
   typedef BwdLayout<N> L;
+  __shared__ __attribute__((aligned(16))) char lds[STAGE_LDS_BYTES];
   const int lane = threadIdx.x & 63, h = lane >> 5, p = lane & 31;
-  const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+  const int wv = threadIdx.x >> 6;
   const long nblk = (npts + 31) >> 5;
-  h8* scr = reinterpret_cast<h8*>(scratch + wave * (long)L::S_KSTEPS * 64 * 16);
+  const long wslot = (long)blockIdx.x * 4 + wv;
+  h8* scr = reinterpret_cast<h8*>(scratch + wslot * (long)L::S_KSTEPS * 64 * 16);
+  b8* scrb = reinterpret_cast<b8*>(scr);
   h8 e0h, e1h; b8 e0b, e1b;
   make_sel<h8>(lane, e0h, e1h);
   make_sel<b8>(lane, e0b, e1b);
+  Stage sg = stage_init(lds);
+  stage_issue<h8, 3>(sg, gtile<h8, 3>(Wf0, o.v[OFF_W0], 0), 0);
 
-  for (long blk = wave; blk < nblk; blk += nwaves) {
-    // opaque per-iteration copies of the parameter pointers: keeps LICM from hoisting ~3000 weight loads
+  // every wavefront of a workgroup runs the same number of iterations (workgroup-uniform loop bound)
+  for (long blk0 = (long)blockIdx.x * 4; blk0 < nblk; blk0 += (long)gridDim.x * 4) {
     const h8* Wf = launder(Wf0);
     const b8* Wb = launder(Wb0);
     const float* T = launder(T0);
-    b8* pblk = panels + blk * (long)L::P_TILES * 128;
+    const long blk = blk0 + wv;
+    const bool live = blk < nblk;
+    b8* pblk = panels + (live ? blk : 0) * (long)L::P_TILES * 128;
     long i = blk * 32 + p;
     const bool valid = i < npts;
     if (!valid) i = npts - 1;
@@ -235,21 +173,33 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PointSrc ps, long npts, co
     pe_compute(x, h, pe);
     h8 pef[3];
     pe_to_frags_f16(pe, x, h, pef);
-    panel_store<h8>(pblk, L::P_H0, lane, pef[0], pef[1], e0h, e1h);
-    panel_store<h8>(pblk, L::P_H0 + 1, lane, pef[2], zero_frag<h8>(), e0h, e1h);
+    pstore<h8>(pblk, live, L::P_H0, lane, pef[0], pef[1], e0h, e1h);
+    pstore<h8>(pblk, live, L::P_H0 + 1, lane, pef[2], zero_frag<h8>(), e0h, e1h);
     h8 hs[N::SK];
     {
+#define AVC_FWD_KEEP(OFFB, OUT, SCR, PT)                                                     \
+  AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);  \
+          acc_to_frags(a, OUT[2 * t], OUT[2 * t + 1]);                                        \
+          scr_store(scr, (SCR) + 2 * t, lane, OUT[2 * t]); scr_store(scr, (SCR) + 2 * t + 1, lane, OUT[2 * t + 1]); \
+          pstore<h8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0h, e1h);)
       h8 h1[N::HK];
-      fwd_layer_keep<N, 3, N::HT>(Wf, o.v[OFF_W0], T + o.v[OFF_B0], lane, h, pef, h1, scr, L::S_H1, pblk, L::P_H1, e0h, e1h);
+      layer_s<h8, 3, N::HT, N::HK>(sg, Wf, o.v[OFF_W0], gtile<h8, N::HK>(Wf, o.v[OFF_WM0], 0), pef,
+                                   AVC_FWD_KEEP(OFF_B0, h1, L::S_H1, L::P_H1));
       h8 hm0[N::HK];
-      fwd_layer_keep<N, N::HK, N::HT>(Wf, o.v[OFF_WM0], T + o.v[OFF_BM0], lane, h, h1, hm0, scr, L::S_HM, pblk, L::P_HM, e0h, e1h);
       if constexpr (N::NMID == 2) {
+        layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM0], gtile<h8, N::HK>(Wf, o.v[OFF_WM1], 0), h1,
+                                         AVC_FWD_KEEP(OFF_BM0, hm0, L::S_HM, L::P_HM));
         h8 hm1[N::HK];
-        fwd_layer_keep<N, N::HK, N::HT>(Wf, o.v[OFF_WM1], T + o.v[OFF_BM1], lane, h, hm0, hm1, scr, L::S_HM + N::HK, pblk,
-                                        L::P_HM + N::HT, e0h, e1h);
-        fwd_layer_keep<N, N::HK, N::ST>(Wf, o.v[OFF_WS], T + o.v[OFF_BS], lane, h, hm1, hs, scr, L::S_HS, pblk, L::P_HS, e0h, e1h);
+        layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM1], gtile<h8, N::HK>(Wf, o.v[OFF_WS], 0), hm0,
+                                         AVC_FWD_KEEP(OFF_BM1, hm1, L::S_HM + N::HK, L::P_HM + N::HT));
+        layer_s<h8, N::HK, N::ST, N::SK>(sg, Wf, o.v[OFF_WS], gtile<h8, N::SK>(Wf, o.v[OFF_WST], 0), hm1,
+                                         AVC_FWD_KEEP(OFF_BS, hs, L::S_HS, L::P_HS));
       } else {
-        fwd_layer_keep<N, N::HK, N::ST>(Wf, o.v[OFF_WS], T + o.v[OFF_BS], lane, h, hm0, hs, scr, L::S_HS, pblk, L::P_HS, e0h, e1h);
+        layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM0], gtile<h8, N::HK>(Wf, o.v[OFF_WS], 0), h1,
+                                         AVC_FWD_KEEP(OFF_BM0, hm0, L::S_HM, L::P_HM));
+        layer_s<h8, N::HK, N::ST, N::SK>(sg, Wf, o.v[OFF_WS], gtile<h8, N::SK>(Wf, o.v[OFF_WST], 0), hm0,
+                                         AVC_FWD_KEEP(OFF_BS, hs, L::S_HS, L::P_HS));
       }
     }
     // ------------------------------------------------------------------ phase B: normal sweep (f16)
@@ -263,38 +213,49 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PointSrc ps, long npts, co
         h8 q;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float sg = sig_from_h((float)hs[s][j]);
-          g_s[s][j] = (_Float16)(w8[j] * sg);
-          q[j] = (_Float16)(w8[j] * AVC_BETA * sg * (1.f - sg) * (1.f / 64.f));
+          const float sg_ = sig_from_h((float)hs[s][j]);
+          g_s[s][j] = (_Float16)(w8[j] * sg_);
+          q[j] = (_Float16)(w8[j] * AVC_BETA * sg_ * (1.f - sg_) * (1.f / 64.f));
         }
         scr_store(scr, L::S_QS + s, lane, q);
       }
 #pragma unroll
-      for (int t = 0; t < N::ST; ++t) panel_store<h8>(pblk, L::P_GAS + t, lane, g_s[2 * t], g_s[2 * t + 1], e0h, e1h);
+      for (int t = 0; t < N::ST; ++t) pstore<h8>(pblk, live, L::P_GAS + t, lane, g_s[2 * t], g_s[2 * t + 1], e0h, e1h);
+      // g_h(prev) = W^T g_a ; g_a(prev) = g_h * sigma(h_prev) ; q = g_h * sp''(h_prev) / 64
+#define AVC_NSTEP(OUT, SH, SQ, PT)                                                                        \
+  AVC_EPI(const h8 hv0 = scr_load(scr, (SH) + 2 * t, lane), hv1 = scr_load(scr, (SH) + 2 * t + 1, lane);   \
+          h8 q0, q1;                                                                                        \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                   \
+            const float s0 = sig_from_h((float)hv0[j]), s1 = sig_from_h((float)hv1[j]);                     \
+            OUT[2 * t][j] = (_Float16)(acc[j] * s0); OUT[2 * t + 1][j] = (_Float16)(acc[8 + j] * s1);        \
+            q0[j] = (_Float16)(acc[j] * AVC_BETA * s0 * (1.f - s0) * (1.f / 64.f));                          \
+            q1[j] = (_Float16)(acc[8 + j] * AVC_BETA * s1 * (1.f - s1) * (1.f / 64.f)); }                    \
+          pin2(OUT[2 * t], OUT[2 * t + 1]);                                                                 \
+          scr_store(scr, (SQ) + 2 * t, lane, q0); scr_store(scr, (SQ) + 2 * t + 1, lane, q1);               \
+          pstore<h8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0h, e1h);)
       h8 g[N::HK];
-      normal_step<N, N::SK, N::HT>(Wf, o.v[OFF_WST], lane, g_s, g, scr, L::S_HM + (N::NMID - 1) * N::HK,
-                                   L::S_QM + (N::NMID - 1) * N::HK, pblk, L::P_GAM + (N::NMID - 1) * N::HT, e0h, e1h);
+      h8 g2[N::HK];
       if constexpr (N::NMID == 2) {
-        h8 g2[N::HK];
-        normal_step<N, N::HK, N::HT>(Wf, o.v[OFF_WM1T], lane, g, g2, scr, L::S_HM, L::S_QM, pblk, L::P_GAM, e0h, e1h);
-        normal_step<N, N::HK, N::HT>(Wf, o.v[OFF_WM0T], lane, g2, g, scr, L::S_H1, L::S_Q1, pblk, L::P_GA1, e0h, e1h);
+        layer_s<h8, N::SK, N::HT, N::HK>(sg, Wf, o.v[OFF_WST], gtile<h8, N::HK>(Wf, o.v[OFF_WM1T], 0), g_s,
+                                         AVC_NSTEP(g, L::S_HM + N::HK, L::S_QM + N::HK, L::P_GAM + N::HT));
+        layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM1T], gtile<h8, N::HK>(Wf, o.v[OFF_WM0T], 0), g,
+                                         AVC_NSTEP(g2, L::S_HM, L::S_QM, L::P_GAM));
+        layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM0T], gtile<h8, N::HK>(Wf, o.v[OFF_W0T], 0), g2,
+                                         AVC_NSTEP(g, L::S_H1, L::S_Q1, L::P_GA1));
       } else {
-        h8 g2[N::HK];
-        normal_step<N, N::HK, N::HT>(Wf, o.v[OFF_WM0T], lane, g, g2, scr, L::S_H1, L::S_Q1, pblk, L::P_GA1, e0h, e1h);
-#pragma unroll
-        for (int s = 0; s < N::HK; ++s) g[s] = g2[s];
+        layer_s<h8, N::SK, N::HT, N::HK>(sg, Wf, o.v[OFF_WST], gtile<h8, N::HK>(Wf, o.v[OFF_WM0T], 0), g_s,
+                                         AVC_NSTEP(g2, L::S_HM, L::S_QM, L::P_GAM));
+        layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM0T], gtile<h8, N::HK>(Wf, o.v[OFF_W0T], 0), g2,
+                                         AVC_NSTEP(g, L::S_H1, L::S_Q1, L::P_GA1));
       }
       float part[3] = {0.f, 0.f, 0.f};
       const float* wpe = T + o.v[OFF_WL0_PE] + h * 24;
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        facc acc = tile_gemm<h8, N::HK>(tptr<h8, N::HK>(Wf, o.v[OFF_W0T], t, lane), g);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
+      layer_s<h8, N::HK, 2, N::SK + 3>(sg, Wf, o.v[OFF_W0T], gtile<h8, N::SK + 3>(Wf, o.v[OFF_WL], 0), g, AVC_EPI(
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {
           const int q = 16 * t + r;
           if (q < 24) part[q % 3] += pe.d[q] * (acc[r] + wpe[q]);
         }
-      }
+      ));
 #pragma unroll
       for (int c = 0; c < 3; ++c) n[c] = xhalf_sum(part[c]);
     }
@@ -302,64 +263,49 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PointSrc ps, long npts, co
     float delta_o[4];   // half 0: outputs 0..3, half 1: outputs 4,5 (delta = d_rgb * rgb (1-rgb))
     {
       h8 feat[N::HK];
-      {
+      layer2_s<h8, N::SK, 3, N::HT, N::HK + 1>(sg, Wf, o.v[OFF_WL], gtile<h8, N::HK + 1>(Wf, o.v[OFF_C0], 0), hs, pef, AVC_EPI(
         float b[16], a[16];
-#pragma unroll
-        for (int t = 0; t < N::HT; ++t) {
-          facc acc = tile_gemm2<h8, N::SK, 3>(tptr<h8, N::SK + 3>(Wf, o.v[OFF_WL], t, lane), hs, pef);
-          load16(T + o.v[OFF_BL], t, h, b);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) a[r] = acc[r] + b[r];
-          acc_to_frags(a, feat[2 * t], feat[2 * t + 1]);
-          panel_store<h8>(pblk, L::P_FEAT + t, lane, feat[2 * t], feat[2 * t + 1], e0h, e1h);
-        }
-      }
+        load16(T + o.v[OFF_BL], t, h, b);
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = acc[r] + b[r];
+        acc_to_frags(a, feat[2 * t], feat[2 * t + 1]);
+        pstore<h8>(pblk, live, L::P_FEAT + t, lane, feat[2 * t], feat[2 * t + 1], e0h, e1h);
+      ));
       h8 xn[1];
       xn[0] = zero_frag<h8>();
       if (h == 0) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) { xn[0][c] = (_Float16)x[c]; xn[0][3 + c] = (_Float16)n[c]; }
       }
-      panel_store<h8>(pblk, L::P_XN, lane, xn[0], zero_frag<h8>(), e0h, e1h);
-      float b[16], a[16];
+      pstore<h8>(pblk, live, L::P_XN, lane, xn[0], zero_frag<h8>(), e0h, e1h);
+#define AVC_RELU_KEEP(OFFB, OUT, SCR, PT)                                                    \
+  AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r] + b[r], 0.f);   \
+          acc_to_frags(a, OUT[2 * t], OUT[2 * t + 1]);                                        \
+          scr_store(scr, (SCR) + 2 * t, lane, OUT[2 * t]); scr_store(scr, (SCR) + 2 * t + 1, lane, OUT[2 * t + 1]); \
+          pstore<h8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0h, e1h);)
       h8 r1[N::HK];
-#pragma unroll
-      for (int t = 0; t < N::HT; ++t) {
-        facc acc = tile_gemm2<h8, N::HK, 1>(tptr<h8, N::HK + 1>(Wf, o.v[OFF_C0], t, lane), feat, xn);
-        load16(T + o.v[OFF_CB0], t, h, b);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r] + b[r], 0.f);
-        acc_to_frags(a, r1[2 * t], r1[2 * t + 1]);
-        scr_store(scr, L::S_R1 + 2 * t, lane, r1[2 * t]);
-        scr_store(scr, L::S_R1 + 2 * t + 1, lane, r1[2 * t + 1]);
-        panel_store<h8>(pblk, L::P_R1 + t, lane, r1[2 * t], r1[2 * t + 1], e0h, e1h);
-      }
-      facc acco;
+      h8 r2[N::HK];
       if constexpr (N::NCMID == 1) {
-        h8 r2[N::HK];
-#pragma unroll
-        for (int t = 0; t < N::HT; ++t) {
-          facc acc = tile_gemm<h8, N::HK>(tptr<h8, N::HK>(Wf, o.v[OFF_CM0], t, lane), r1);
-          load16(T + o.v[OFF_CBM0], t, h, b);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r] + b[r], 0.f);
-          acc_to_frags(a, r2[2 * t], r2[2 * t + 1]);
-          scr_store(scr, L::S_R2 + 2 * t, lane, r2[2 * t]);
-          scr_store(scr, L::S_R2 + 2 * t + 1, lane, r2[2 * t + 1]);
-          panel_store<h8>(pblk, L::P_R2 + t, lane, r2[2 * t], r2[2 * t + 1], e0h, e1h);
-        }
-        acco = tile_gemm<h8, N::HK>(tptr<h8, N::HK>(Wf, o.v[OFF_CH], 0, lane), r2);
+        layer2_s<h8, N::HK, 1, N::HT, N::HK>(sg, Wf, o.v[OFF_C0], gtile<h8, N::HK>(Wf, o.v[OFF_CM0], 0), feat, xn,
+                                             AVC_RELU_KEEP(OFF_CB0, r1, L::S_R1, L::P_R1));
+        layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_CM0], gtile<h8, N::HK>(Wf, o.v[OFF_CH], 0), r1,
+                                         AVC_RELU_KEEP(OFF_CBM0, r2, L::S_R2, L::P_R2));
       } else {
-        acco = tile_gemm<h8, N::HK>(tptr<h8, N::HK>(Wf, o.v[OFF_CH], 0, lane), r1);
-      }
-      load16(T + o.v[OFF_CBH], 0, h, b);
+        layer2_s<h8, N::HK, 1, N::HT, N::HK>(sg, Wf, o.v[OFF_C0], gtile<h8, N::HK>(Wf, o.v[OFF_CH], 0), feat, xn,
+                                             AVC_RELU_KEEP(OFF_CB0, r1, L::S_R1, L::P_R1));
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float rgb = sigmoidf_(acco[r] + b[r]);
-        const int ch = h ? 4 + r : r;
-        const float dr = (ch < 6) ? d_rgb[6 * i + (ch < 6 ? ch : 0)] * vmask : 0.f;
-        delta_o[r] = dr * rgb * (1.f - rgb);
+        for (int s = 0; s < N::HK; ++s) r2[s] = r1[s];
       }
+      layer_s<h8, N::HK, 1, 1>(sg, Wf, o.v[OFF_CH], gtile<b8, 1>(Wb, o.v[OFF_CHT], 0), r2, AVC_EPI(
+        float b[16];
+        load16(T + o.v[OFF_CBH], 0, h, b);
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {
+          const float rgb = sigmoidf_(acc[r] + b[r]);
+          const int ch = h ? 4 + r : r;
+          const float dr = (ch < 6) ? d_rgb[6 * i + (ch < 6 ? ch : 0)] * vmask : 0.f;
+          delta_o[r] = dr * rgb * (1.f - rgb);
+        }
+      ));
     }
     // ------------------------------------------------------------------ phase D: colour backward (bf16)
     float nbar[3];
@@ -369,63 +315,50 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PointSrc ps, long npts, co
       dof[0] = zero_frag<b8>();
 #pragma unroll
       for (int r = 0; r < 4; ++r) dof[0][r] = (__bf16)delta_o[r];
-      panel_store<b8>(pblk, L::P_DO, lane, dof[0], zero_frag<b8>(), e0b, e1b);
-      b8 dl[N::HK];   // delta of the last hidden colour layer
-      {
-        const int scr_r = (N::NCMID == 1) ? L::S_R2 : L::S_R1;
-        const int pt = (N::NCMID == 1) ? L::P_D2 : L::P_D1;
-#pragma unroll
-        for (int t = 0; t < N::HT; ++t) {
-          facc acc = tile_gemm<b8, 1>(tptr<b8, 1>(Wb, o.v[OFF_CHT], t, lane), dof);
-          const h8 rv0 = scr_load(scr, scr_r + 2 * t, lane), rv1 = scr_load(scr, scr_r + 2 * t + 1, lane);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            dl[2 * t][j] = (__bf16)((float)rv0[j] > 0.f ? acc[j] : 0.f);
-            dl[2 * t + 1][j] = (__bf16)((float)rv1[j] > 0.f ? acc[8 + j] : 0.f);
-          }
-          panel_store<b8>(pblk, pt + t, lane, dl[2 * t], dl[2 * t + 1], e0b, e1b);
-        }
-      }
+      pstore<b8>(pblk, live, L::P_DO, lane, dof[0], zero_frag<b8>(), e0b, e1b);
+#define AVC_RELU_BWD(OUT, SR, PT)                                                                          \
+  AVC_EPI(const h8 rv0 = scr_load(scr, (SR) + 2 * t, lane), rv1 = scr_load(scr, (SR) + 2 * t + 1, lane);    \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                    \
+            OUT[2 * t][j] = (__bf16)((float)rv0[j] > 0.f ? acc[j] : 0.f);                                    \
+            OUT[2 * t + 1][j] = (__bf16)((float)rv1[j] > 0.f ? acc[8 + j] : 0.f); }                          \
+          pin2(OUT[2 * t], OUT[2 * t + 1]);                                                                  \
+          pstore<b8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0b, e1b);)
+      b8 dl[N::HK];
+      b8 d1[N::HK];
       if constexpr (N::NCMID == 1) {
-        b8 d1[N::HK];
-#pragma unroll
-        for (int t = 0; t < N::HT; ++t) {
-          facc acc = tile_gemm<b8, N::HK>(tptr<b8, N::HK>(Wb, o.v[OFF_CM0T], t, lane), dl);
-          const h8 rv0 = scr_load(scr, L::S_R1 + 2 * t, lane), rv1 = scr_load(scr, L::S_R1 + 2 * t + 1, lane);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            d1[2 * t][j] = (__bf16)((float)rv0[j] > 0.f ? acc[j] : 0.f);
-            d1[2 * t + 1][j] = (__bf16)((float)rv1[j] > 0.f ? acc[8 + j] : 0.f);
+        layer_s<b8, 1, N::HT, N::HK>(sg, Wb, o.v[OFF_CHT], gtile<b8, N::HK>(Wb, o.v[OFF_CM0T], 0), dof,
+                                     AVC_RELU_BWD(dl, L::S_R2, L::P_D2));
+        layer_s<b8, N::HK, N::HT, N::HK>(sg, Wb, o.v[OFF_CM0T], gtile<b8, N::HK>(Wb, o.v[OFF_C0T], 0), dl,
+                                         AVC_RELU_BWD(d1, L::S_R1, L::P_D1));
+      } else {
+        layer_s<b8, 1, N::HT, N::HK>(sg, Wb, o.v[OFF_CHT], gtile<b8, N::HK>(Wb, o.v[OFF_C0T], 0), dof,
+                                     AVC_RELU_BWD(d1, L::S_R1, L::P_D1));
+      }
+      // d r0 = C0^T delta1: HT feature tiles, then the [x,n] tile (rows 3,4,5 = d n)
+      float dn_acc[3] = {0.f, 0.f, 0.f};
+      layer_s<b8, N::HK, N::HT + 1, 3>(sg, Wb, o.v[OFF_C0T], gtile<b8, 3>(Wb, o.v[OFF_W0], 0), d1, AVC_EPI(
+        if (t < N::HT) {
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) {
+            dfeat[2 * (t < N::HT ? t : 0)][j] = (__bf16)acc[j];
+            dfeat[2 * (t < N::HT ? t : 0) + 1][j] = (__bf16)acc[8 + j];
           }
-          panel_store<b8>(pblk, L::P_D1 + t, lane, d1[2 * t], d1[2 * t + 1], e0b, e1b);
+          pin2(dfeat[2 * (t < N::HT ? t : 0)], dfeat[2 * (t < N::HT ? t : 0) + 1]);
+          pstore<b8>(pblk, live, L::P_DFEAT + t, lane, dfeat[2 * (t < N::HT ? t : 0)], dfeat[2 * (t < N::HT ? t : 0) + 1], e0b, e1b);
+        } else {
+          dn_acc[0] = acc[3]; dn_acc[1] = acc[0]; dn_acc[2] = acc[1];
         }
-#pragma unroll
-        for (int s = 0; s < N::HK; ++s) dl[s] = d1[s];
-      }
-      // d r0 = C0^T delta1: rows = feature (HT tiles) then the [x,n] tile
-#pragma unroll
-      for (int t = 0; t < N::HT; ++t) {
-        facc acc = tile_gemm<b8, N::HK>(tptr<b8, N::HK>(Wb, o.v[OFF_C0T], t, lane), dl);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { dfeat[2 * t][j] = (__bf16)acc[j]; dfeat[2 * t + 1][j] = (__bf16)acc[8 + j]; }
-        panel_store<b8>(pblk, L::P_DFEAT + t, lane, dfeat[2 * t], dfeat[2 * t + 1], e0b, e1b);
-      }
+      ));
       {
-        facc acc = tile_gemm<b8, N::HK>(tptr<b8, N::HK>(Wb, o.v[OFF_C0T], N::HT, lane), dl);
-        // rows 3,4,5 = d n : row 3 -> (h0,r3), row 4 -> (h1,r0), row 5 -> (h1,r1)
-        const float a3 = acc[3], a0 = acc[0], a1 = acc[1];
+        // row 3 -> (h0,r3), row 4 -> (h1,r0), row 5 -> (h1,r1)
+        const float a3 = dn_acc[0], a0 = dn_acc[1], a1 = dn_acc[2];
         const float o3 = __shfl_xor(a3, 32), o0 = __shfl_xor(a0, 32), o1 = __shfl_xor(a1, 32);
-        const float dn0 = h ? o3 : a3;
-        const float dn1 = h ? a0 : o0;
-        const float dn2 = h ? a1 : o1;
-        nbar[0] = d_normal[3 * i + 0] * vmask + dn0;
-        nbar[1] = d_normal[3 * i + 1] * vmask + dn1;
-        nbar[2] = d_normal[3 * i + 2] * vmask + dn2;
+        nbar[0] = d_normal[3 * i + 0] * vmask + (h ? o3 : a3);
+        nbar[1] = d_normal[3 * i + 1] * vmask + (h ? a0 : o0);
+        nbar[2] = d_normal[3 * i + 2] * vmask + (h ? a1 : o1);
       }
     }
     const float dsdf = d_sdf[i] * vmask;
-    // A-panels with a single live feature: d_sdf and the constant 1 (row 0 of the last layer)
-    {
+    if (live) {   // A-panels with a single live feature: d_sdf and the constant 1 (row 0 of the last layer)
       const int nf = lane & 31;
       b8 k0 = zero_frag<b8>(), k1 = zero_frag<b8>(), o0 = zero_frag<b8>(), o1 = zero_frag<b8>();
       if (nf == 0) {
@@ -438,8 +371,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PointSrc ps, long npts, co
           if (r < 8) { k0[r] = (__bf16)v; o0[r] = (__bf16)one; } else { k1[r - 8] = (__bf16)v; o1[r - 8] = (__bf16)one; }
         }
       }
-      b8* d1 = pblk + (long)L::P_SDF * 128 + lane; d1[0] = k0; d1[64] = k1;
-      b8* d2 = pblk + (long)L::P_ONE * 128 + lane; d2[0] = o0; d2[64] = o1;
+      b8* dd1 = pblk + (long)L::P_SDF * 128 + lane; dd1[0] = k0; dd1[64] = k1;
+      b8* dd2 = pblk + (long)L::P_ONE * 128 + lane; dd2[0] = o0; dd2[64] = o1;
     }
     // ------------------------------------------------------------------ phase E: second-order sweep (i) (bf16)
     b8 aps[N::SK];   // abar'_s stays in registers into phase F
@@ -447,51 +380,78 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PointSrc ps, long npts, co
       b8 gb0[3];
 #pragma unroll
       for (int q = 0; q < 24; ++q) gb0[q >> 3][q & 7] = (__bf16)(pe.d[q] * nbar[q % 3]);
-      panel_store<b8>(pblk, L::P_GB0, lane, gb0[0], gb0[1], e0b, e1b);
-      panel_store<b8>(pblk, L::P_GB0 + 1, lane, gb0[2], zero_frag<b8>(), e0b, e1b);
-      b8 dummy[2 * N::HT];
+      pstore<b8>(pblk, live, L::P_GB0, lane, gb0[0], gb0[1], e0b, e1b);
+      pstore<b8>(pblk, live, L::P_GB0 + 1, lane, gb0[2], zero_frag<b8>(), e0b, e1b);
+      // gbar_a = W gbar_h(in); abar' = gbar_a * q * 64 ; gbar_h(out) = gbar_a * sigma(h_out)
+#define AVC_SECOND(OUT, SH, SQ, SAP, PT, KEEP)                                                              \
+  AVC_EPI(const h8 hv0 = scr_load(scr, (SH) + 2 * t, lane), hv1 = scr_load(scr, (SH) + 2 * t + 1, lane);    \
+          const h8 q0 = scr_load(scr, (SQ) + 2 * t, lane), q1 = scr_load(scr, (SQ) + 2 * t + 1, lane);      \
+          b8 a0, a1;                                                                                         \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                    \
+            OUT[2 * t][j] = (__bf16)(acc[j] * sig_from_h((float)hv0[j]));                                    \
+            OUT[2 * t + 1][j] = (__bf16)(acc[8 + j] * sig_from_h((float)hv1[j]));                            \
+            a0[j] = (__bf16)(acc[j] * (float)q0[j] * 64.f); a1[j] = (__bf16)(acc[8 + j] * (float)q1[j] * 64.f); } \
+          pin2(OUT[2 * t], OUT[2 * t + 1]);                                                                  \
+          if (KEEP) { aps[2 * (KEEP ? t : 0)] = a0; aps[2 * (KEEP ? t : 0) + 1] = a1; }                      \
+          else { scr_store(scrb, (SAP) + 2 * t, lane, a0); scr_store(scrb, (SAP) + 2 * t + 1, lane, a1); }   \
+          pstore<b8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0b, e1b);)
       b8 gb1[N::HK];
-      second_step<N, 3, N::HT, false>(Wb, o.v[OFF_W0], lane, gb0, gb1, scr, L::S_H1, L::S_Q1, L::S_AP1, dummy, pblk, L::P_GBH1, e0b, e1b);
+      layer_s<b8, 3, N::HT, N::HK>(sg, Wb, o.v[OFF_W0], gtile<b8, N::HK>(Wb, o.v[OFF_WM0], 0), gb0,
+                                   AVC_SECOND(gb1, L::S_H1, L::S_Q1, L::S_AP1, L::P_GBH1, false));
       b8 gbm[N::HK];
-      second_step<N, N::HK, N::HT, false>(Wb, o.v[OFF_WM0], lane, gb1, gbm, scr, L::S_HM, L::S_QM, L::S_APM, dummy, pblk, L::P_GBHM, e0b, e1b);
       b8 gbs[N::SK];
       if constexpr (N::NMID == 2) {
+        layer_s<b8, N::HK, N::HT, N::HK>(sg, Wb, o.v[OFF_WM0], gtile<b8, N::HK>(Wb, o.v[OFF_WM1], 0), gb1,
+                                         AVC_SECOND(gbm, L::S_HM, L::S_QM, L::S_APM, L::P_GBHM, false));
         b8 gbm1[N::HK];
-        second_step<N, N::HK, N::HT, false>(Wb, o.v[OFF_WM1], lane, gbm, gbm1, scr, L::S_HM + N::HK, L::S_QM + N::HK,
-                                            L::S_APM + N::HK, dummy, pblk, L::P_GBHM + N::HT, e0b, e1b);
-        second_step<N, N::HK, N::ST, true>(Wb, o.v[OFF_WS], lane, gbm1, gbs, scr, L::S_HS, L::S_QS, 0, aps, pblk, L::P_GBHS, e0b, e1b);
+        layer_s<b8, N::HK, N::HT, N::HK>(sg, Wb, o.v[OFF_WM1], gtile<b8, N::HK>(Wb, o.v[OFF_WS], 0), gbm,
+                                         AVC_SECOND(gbm1, L::S_HM + N::HK, L::S_QM + N::HK, L::S_APM + N::HK, L::P_GBHM + N::HT, false));
+        layer_s<b8, N::HK, N::ST, N::HK>(sg, Wb, o.v[OFF_WS], gtile<b8, N::HK>(Wb, o.v[OFF_WLT], 0), gbm1,
+                                         AVC_SECOND(gbs, L::S_HS, L::S_QS, 0, L::P_GBHS, true));
       } else {
-        second_step<N, N::HK, N::ST, true>(Wb, o.v[OFF_WS], lane, gbm, gbs, scr, L::S_HS, L::S_QS, 0, aps, pblk, L::P_GBHS, e0b, e1b);
+        layer_s<b8, N::HK, N::HT, N::HK>(sg, Wb, o.v[OFF_WM0], gtile<b8, N::HK>(Wb, o.v[OFF_WS], 0), gb1,
+                                         AVC_SECOND(gbm, L::S_HM, L::S_QM, L::S_APM, L::P_GBHM, false));
+        layer_s<b8, N::HK, N::ST, N::HK>(sg, Wb, o.v[OFF_WS], gtile<b8, N::HK>(Wb, o.v[OFF_WLT], 0), gbm,
+                                         AVC_SECOND(gbs, L::S_HS, L::S_QS, 0, L::P_GBHS, true));
       }
     }
     // ------------------------------------------------------------------ phase F: reverse sweep (ii) (bf16)
     {
       b8 as_[N::SK];
-      float wa[16];
-#pragma unroll
-      for (int t = 0; t < N::ST; ++t) {
-        // ubar[:SKIP]/sqrt2 = (W_last[1:,:]^T dfeat + W_last[0,:] d_sdf)/sqrt2 ; 1/sqrt2 is folded into both packs
-        facc acc = tile_gemm<b8, N::HK>(tptr<b8, N::HK>(Wb, o.v[OFF_WLT], t, lane), dfeat);
+      // ubar[:SKIP]/sqrt2 = (W_last[1:,:]^T dfeat + W_last[0,:] d_sdf)/sqrt2 ; 1/sqrt2 is folded into both packs
+      layer_s<b8, N::HK, N::ST, N::SK>(sg, Wb, o.v[OFF_WLT], gtile<b8, N::SK>(Wb, o.v[OFF_WST], 0), dfeat, AVC_EPI(
+        float wa[16];
         load16(T + o.v[OFF_WL0_ACC], t, h, wa);
         const h8 hv0 = scr_load(scr, L::S_HS + 2 * t, lane), hv1 = scr_load(scr, L::S_HS + 2 * t + 1, lane);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {
           as_[2 * t][j] = (__bf16)((float)aps[2 * t][j] + (acc[j] + wa[j] * dsdf) * sig_from_h((float)hv0[j]));
           as_[2 * t + 1][j] = (__bf16)((float)aps[2 * t + 1][j] + (acc[8 + j] + wa[8 + j] * dsdf) * sig_from_h((float)hv1[j]));
         }
-        panel_store<b8>(pblk, L::P_ABS + t, lane, as_[2 * t], as_[2 * t + 1], e0b, e1b);
-      }
+        pin2(as_[2 * t], as_[2 * t + 1]);
+        pstore<b8>(pblk, live, L::P_ABS + t, lane, as_[2 * t], as_[2 * t + 1], e0b, e1b);
+      ));
+      // hbar(prev) = W^T abar(cur); abar(prev) = abar'(prev) + hbar * sigma(h_prev)
+#define AVC_REVERSE(OUT, SH, SAP, PT)                                                                       \
+  AVC_EPI(const h8 hv0 = scr_load(scr, (SH) + 2 * t, lane), hv1 = scr_load(scr, (SH) + 2 * t + 1, lane);    \
+          const b8 p0 = scr_load(scrb, (SAP) + 2 * t, lane), p1 = scr_load(scrb, (SAP) + 2 * t + 1, lane);  \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                    \
+            OUT[2 * t][j] = (__bf16)((float)p0[j] + acc[j] * sig_from_h((float)hv0[j]));                     \
+            OUT[2 * t + 1][j] = (__bf16)((float)p1[j] + acc[8 + j] * sig_from_h((float)hv1[j])); }           \
+          pin2(OUT[2 * t], OUT[2 * t + 1]);                                                                  \
+          pstore<b8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0b, e1b);)
       b8 am[N::HK];
-      reverse_step<N, N::SK, N::HT>(Wb, o.v[OFF_WST], lane, as_, am, scr, L::S_HM + (N::NMID - 1) * N::HK,
-                                    L::S_APM + (N::NMID - 1) * N::HK, pblk, L::P_ABM + (N::NMID - 1) * N::HT, e0b, e1b);
+      b8 am0[N::HK];
+      const void* first = gtile<h8, 3>(Wf0, o.v[OFF_W0], 0);   // prefetch the first tile of the next block iteration
       if constexpr (N::NMID == 2) {
-        b8 am0[N::HK];
-        reverse_step<N, N::HK, N::HT>(Wb, o.v[OFF_WM1T], lane, am, am0, scr, L::S_HM, L::S_APM, pblk, L::P_ABM, e0b, e1b);
-        b8 a1[N::HK];
-        reverse_step<N, N::HK, N::HT>(Wb, o.v[OFF_WM0T], lane, am0, a1, scr, L::S_H1, L::S_AP1, pblk, L::P_AB1, e0b, e1b);
+        layer_s<b8, N::SK, N::HT, N::HK>(sg, Wb, o.v[OFF_WST], gtile<b8, N::HK>(Wb, o.v[OFF_WM1T], 0), as_,
+                                         AVC_REVERSE(am, L::S_HM + N::HK, L::S_APM + N::HK, L::P_ABM + N::HT));
+        layer_s<b8, N::HK, N::HT, N::HK>(sg, Wb, o.v[OFF_WM1T], gtile<b8, N::HK>(Wb, o.v[OFF_WM0T], 0), am,
+                                         AVC_REVERSE(am0, L::S_HM, L::S_APM, L::P_ABM));
+        layer_s<b8, N::HK, N::HT, 3>(sg, Wb, o.v[OFF_WM0T], first, am0, AVC_REVERSE(am, L::S_H1, L::S_AP1, L::P_AB1));
       } else {
-        b8 a1[N::HK];
-        reverse_step<N, N::HK, N::HT>(Wb, o.v[OFF_WM0T], lane, am, a1, scr, L::S_H1, L::S_AP1, pblk, L::P_AB1, e0b, e1b);
+        layer_s<b8, N::SK, N::HT, N::HK>(sg, Wb, o.v[OFF_WST], gtile<b8, N::HK>(Wb, o.v[OFF_WM0T], 0), as_,
+                                         AVC_REVERSE(am, L::S_HM, L::S_APM, L::P_ABM));
+        layer_s<b8, N::HK, N::HT, 3>(sg, Wb, o.v[OFF_WM0T], first, am, AVC_REVERSE(am0, L::S_H1, L::S_AP1, L::P_AB1));
       }
     }
   }
@@ -506,10 +466,11 @@ extern "C" int avc_render_points_bwd(int net, const float* pts, const float* ray
   for (int k = 0; k < OFF_COUNT; ++k) o.v[k] = offs[k];
   PointSrc ps{pts, rays_o, rays_d, z, S, ldz, pts ? 0 : 1, sample_dist};
   const long nblk = (npts + 31) / 32;
-  long nw = nblk < max_waves ? nblk : max_waves;
-  int grid = (int)((nw + 3) / 4);
+  long ngroups = (nblk + 3) / 4;
+  long maxg = max_waves / 4;
+  if (maxg < 1) maxg = 1;
+  int grid = (int)(ngroups < maxg ? ngroups : maxg);
   if (grid < 1) grid = 1;
-  if ((long)grid * 4 > max_waves && max_waves >= 4) grid = (int)(max_waves / 4);
   hipStream_t s = (hipStream_t)stream;
   if (net == AVC_NET_FULL)
     hipLaunchKernelGGL((mlp_bwd_kernel<NetFull>), dim3(grid), dim3(256), 0, s, ps, npts, (const h8*)wf16, (const b8*)wbf16,

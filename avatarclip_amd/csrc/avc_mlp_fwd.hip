@@ -6,48 +6,52 @@
 #include "../../include/avc.h"
 
 template <class N, int MODE>
-__global__ __launch_bounds__(256) void mlp_fwd_kernel(PointSrc ps, long npts, const h8* __restrict__ Wf,
-                                                      const float* __restrict__ T, AvcOffsets o,
-                                                      float* __restrict__ sdf_out, const int* __restrict__ slot,
-                                                      int ld_out, float* __restrict__ normal_out,
-                                                      float* __restrict__ rgb_out) {
+__global__ __launch_bounds__(256, MODE == 0 ? 2 : 1) void mlp_fwd_kernel(PointSrc ps, long npts, const h8* __restrict__ Wf,
+                                                                       const float* __restrict__ T, AvcOffsets o,
+                                                                       float* __restrict__ sdf_out, const int* __restrict__ slot,
+                                                                       int ld_out, float* __restrict__ normal_out,
+                                                                       float* __restrict__ rgb_out) {
+  __shared__ __attribute__((aligned(16))) char lds[STAGE_LDS_BYTES];
   const int lane = threadIdx.x & 63;
   const int h = lane >> 5;
   const int p = lane & 31;
-  // one wavefront per 32-point block, no persistent loop: a loop would let LICM hoist every (loop-invariant)
-  // weight fragment load out of it and spill ~2000 VGPRs
+  // one wavefront per 32-point block; the wavefronts of a workgroup share every weight tile through LDS, so no wave
+  // may leave early: blocks past the end are clamped to the last point and only their stores are suppressed.
+  // (No persistent loop: LICM would hoist the loop-invariant weight traffic and spill.)
   const long blk = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (blk >= ((npts + 31) >> 5)) return;
-  {
-    long i = blk * 32 + p;
-    const bool valid = i < npts;
-    if (!valid) i = npts - 1;
-    FwdState<N> st;
-    fetch_point(ps, i, st.x);
-    sdf_trunk<N>(Wf, T, o, lane, h, st);
-    long oi = i;
-    if (slot) {
-      const long ray = i / ps.S;
-      oi = ray * ld_out + slot[i];
-    }
-    if (MODE == 0) {
-      if (valid && h == 0) sdf_out[oi] = st.sdf;
-      return;
-    }
-    h8 feat[N::HK];
-    sdf_feature<N>(Wf, T, o, lane, h, st, feat);
-    float n[3];
-    sdf_normal<N>(Wf, T, o, lane, h, st, n);
-    float rgb[4];
-    color_forward<N>(Wf, T, o, lane, h, st.x, n, feat, rgb);
-    if (valid) {
-      if (h == 0) {
-        sdf_out[oi] = st.sdf;
-        normal_out[3 * oi + 0] = n[0]; normal_out[3 * oi + 1] = n[1]; normal_out[3 * oi + 2] = n[2];
-        rgb_out[6 * oi + 0] = rgb[0]; rgb_out[6 * oi + 1] = rgb[1]; rgb_out[6 * oi + 2] = rgb[2]; rgb_out[6 * oi + 3] = rgb[3];
-      } else {
-        rgb_out[6 * oi + 4] = rgb[0]; rgb_out[6 * oi + 5] = rgb[1];
-      }
+  long i = blk * 32 + p;
+  const bool valid = i < npts;
+  if (!valid) i = npts - 1;
+  Stage sg = stage_init(lds);
+  stage_issue<h8, 3>(sg, gtile<h8, 3>(Wf, o.v[OFF_W0], 0), 0);
+  float x0[3];
+  fetch_point(ps, i, x0);
+  long oi = i;
+  if (slot) {
+    const long ray = i / ps.S;
+    oi = ray * ld_out + slot[i];
+  }
+  if (MODE == 0) {
+    const float sdfv = sdf_only<N>(sg, Wf, T, o, h, x0);
+    if (valid && h == 0) sdf_out[oi] = sdfv;
+    return;
+  }
+  FwdState<N> st;
+  st.x[0] = x0[0]; st.x[1] = x0[1]; st.x[2] = x0[2];
+  sdf_trunk<N, N::SK + 3>(sg, Wf, T, o, h, st, gtile<h8, N::SK + 3>(Wf, o.v[OFF_WL], 0));
+  h8 feat[N::HK];
+  sdf_feature<N, N::SK>(sg, Wf, T, o, h, st, feat, gtile<h8, N::SK>(Wf, o.v[OFF_WST], 0));
+  float n[3];
+  sdf_normal<N, N::HK + 1>(sg, Wf, T, o, h, st, n, gtile<h8, N::HK + 1>(Wf, o.v[OFF_C0], 0));
+  float rgb[4];
+  color_forward<N>(sg, Wf, T, o, h, st.x, n, feat, rgb);
+  if (valid) {
+    if (h == 0) {
+      sdf_out[oi] = st.sdf;
+      normal_out[3 * oi + 0] = n[0]; normal_out[3 * oi + 1] = n[1]; normal_out[3 * oi + 2] = n[2];
+      rgb_out[6 * oi + 0] = rgb[0]; rgb_out[6 * oi + 1] = rgb[1]; rgb_out[6 * oi + 2] = rgb[2]; rgb_out[6 * oi + 3] = rgb[3];
+    } else {
+      rgb_out[6 * oi + 4] = rgb[0]; rgb_out[6 * oi + 5] = rgb[1];
     }
   }
 }
@@ -67,12 +71,13 @@ static int launch_fwd(int net, PointSrc ps, long npts, const void* wf, const flo
   AvcOffsets o;
   for (int k = 0; k < OFF_COUNT; ++k) o.v[k] = offs[k];
   hipStream_t s = (hipStream_t)stream;
-  const int grid = grid_for(npts, 4, 0x7fffffff);
+  const int wpb = 4;   // wavefronts per workgroup
+  const int grid = grid_for(npts, wpb, 0x7fffffff);
   if (net == AVC_NET_FULL)
-    hipLaunchKernelGGL((mlp_fwd_kernel<NetFull, MODE>), dim3(grid), dim3(256), 0, s, ps, npts, (const h8*)wf, tab, o,
+    hipLaunchKernelGGL((mlp_fwd_kernel<NetFull, MODE>), dim3(grid), dim3(64 * wpb), 0, s, ps, npts, (const h8*)wf, tab, o,
                        sdf_out, slot, ld_out, normal_out, rgb_out);
   else if (net == AVC_NET_SMALL)
-    hipLaunchKernelGGL((mlp_fwd_kernel<NetSmall, MODE>), dim3(grid), dim3(256), 0, s, ps, npts, (const h8*)wf, tab, o,
+    hipLaunchKernelGGL((mlp_fwd_kernel<NetSmall, MODE>), dim3(grid), dim3(64 * wpb), 0, s, ps, npts, (const h8*)wf, tab, o,
                        sdf_out, slot, ld_out, normal_out, rgb_out);
   else {
     avc_set_error("unknown net id");

@@ -72,6 +72,7 @@ class Engine:
     _by_net = weakref.WeakKeyDictionary()
     PROFILE = False               # bench.py: record (name, points, start_event, end_event) per kernel launch group
     prof_events = []
+    WG_NSPLIT = 512               # split-K workgroups per weight-gradient pair (2 per CU)
     MAX_BWD_WAVES = 1024          # 256 CUs x 4 wavefronts (one per SIMD: the backward kernel uses the full RF)
     PANEL_BYTES_BUDGET = 12 << 30  # weight-gradient operand panels per chunk of points
 
@@ -90,6 +91,8 @@ class Engine:
         assert self.scr_bytes == self.dl.lay.scratch_ksteps * 1024
         self._scratch = None
         self._panels = None
+        self._partials = None
+        self._bpartials = None
         self._packed_key = None
         self._packed = None
 
@@ -220,6 +223,10 @@ class Engine:
         scratch, panels = self._bufs(nblk_max)
         gout = torch.zeros(lay.gout_size, device=self.device, dtype=torch.float32)
         gbias = torch.zeros(max(lay.gbias_size, 1), device=self.device, dtype=torch.float32)
+        nsplit = self.WG_NSPLIT
+        if self._partials is None:
+            self._partials = torch.empty(nsplit, lay.gout_size, device=self.device, dtype=torch.float32)
+            self._bpartials = torch.empty(nsplit, max(lay.gbias_size, 1), device=self.device, dtype=torch.float32)
         st = L.stream()
         esz = 4
         for r0 in range(0, R, rays_per_chunk):
@@ -233,12 +240,15 @@ class Engine:
                     L.ptr(pk.w_bf16), L.ptr(pk.tab), self.dl.offsets, d_sdf.data_ptr() + r0 * S * esz,
                     d_n.data_ptr() + r0 * S * 3 * esz, d_rgb.data_ptr() + r0 * S * 6 * esz, L.ptr(panels),
                     self.MAX_BWD_WAVES, L.ptr(scratch), st), "avc_render_points_bwd")
-            nsplit = max(1, min(nblk, 1024 // 8))
+            ns = max(1, min(nblk, nsplit))
             with Engine._Timed("avc_weight_grad(all pairs)", npts):
                 for (pa, ta, pb, tb, out_off, bias_off) in lay.pairs:
-                    bptr = gbias.data_ptr() + bias_off * 4 if bias_off >= 0 else None
+                    bptr = self._bpartials.data_ptr() + bias_off * 4 if bias_off >= 0 else None
                     L.check(self.lib.avc_weight_grad(L.ptr(panels), self.ptiles, pa, ta, pb, tb, nblk,
-                                                     gout.data_ptr() + out_off * 4, bptr, nsplit, st), "avc_weight_grad")
+                                                     self._partials.data_ptr() + out_off * 4, bptr, ns,
+                                                     self._partials.stride(0), self._bpartials.stride(0), st), "avc_weight_grad")
+                gout += self._partials[:ns].sum(0)
+                gbias += self._bpartials[:ns].sum(0)
         grad = torch.zeros(lay.nparam, device=self.device, dtype=torch.float32)
         grad.index_add_(0, self.dl.un_tgt, gout[self.dl.un_src] * self.dl.un_scale)
         if lay.gbias_size:

@@ -79,11 +79,12 @@ int avc_render_points_bwd(int net, const float* pts, const float* rays_o, const 
                           const float* tab, const int* offs /* host */, const float* d_sdf, const float* d_normal,
                           const float* d_rgb, void* panels, long max_waves, float* scratch, void* stream);
 
-/* out[ta,tb,64,16] += sum over `nblk` 32-point blocks of A-panel tile (pa+ta) x B-panel tile (pb+tb), K = points;
- * lane (n,h), reg r of tile (ta,tb) is dW[32 ta + (r&3)+8(r>>2)+4h][32 tb + n].  bias_out (may be NULL)
- * receives sum_points A[:, 32 ta + n].  nsplit = split-K factor (partials combined with fp32 atomics). */
-int avc_weight_grad(const void* panels, int ptiles, int pa, int ta, int pb, int tb, long nblk, float* out,
-                    float* bias_out, int nsplit, void* stream);
+/* partial[split][ta,tb,64,16] = sum over the split's share of `nblk` 32-point blocks of A-panel tile (pa+ta) x B-panel
+ * tile (pb+tb), K = points; lane (n,h), reg r of tile (ta,tb) is dW[32 ta + (r&3)+8(r>>2)+4h][32 tb + n].
+ * bias_partial[split][32 ta] (may be NULL) receives sum_points A[:, 32 ta + n].  nsplit = split-K factor = grid size;
+ * split s writes its slab at partial + s*out_stride (bias_partial + s*bias_stride), floats; the caller sums the slabs. */
+int avc_weight_grad(const void* panels, int ptiles, int pa, int ta, int pb, int tb, long nblk, float* partial,
+                    float* bias_partial, int nsplit, int out_stride, int bias_stride, void* stream);
 
 /* ---- CLIP ViT-B/32 image encoder (perceptor.encode_image, main.py:512,518,524; OpenAI clip/model.py) ----
  * y[M,N] = act(x[M,K] W^T + bias) (+ residual); W pre-packed bf16 [N/32][K/16][64][8] (lane (n,h): W[32t+n][16s+8h+j]).

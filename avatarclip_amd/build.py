@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libavc.so")
 SOURCES = ["avc_core.hip", "avc_mlp_fwd.hip", "avc_mlp_bwd.hip", "avc_rays.hip", "avc_vit.hip"]
 HEADERS = ["avc_common.h", "avc_mlp.h", os.path.join("..", "..", "include", "avc.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"] + os.environ.get("AVC_EXTRA_FLAGS", "").split()
 
 
 def _hipcc():

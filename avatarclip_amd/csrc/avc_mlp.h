@@ -53,42 +53,91 @@ __device__ __forceinline__ const V* tptr(const V* blob, int off, int t, int lane
 }
 
 
-// ---- staged, software-pipelined layer: tile t's MFMAs are issued before the epilogue of tile t-1, so the VALU /
-// ---- transcendental work of one tile hides under the matrix pipe of the next (same basic block, no barrier between).
+// ---- tile geometry of every packed weight (k-steps per tile, tiles) ----
+template <class N, int OFF> struct TileInfo;
+#define AVC_TI(OFF, KS_, NT_) template <class N> struct TileInfo<N, OFF> { static constexpr int KS = KS_, NT = NT_; };
+AVC_TI(OFF_W0, 3, N::HT)          AVC_TI(OFF_WM0, N::HK, N::HT)   AVC_TI(OFF_WM1, N::HK, N::HT)  AVC_TI(OFF_WS, N::HK, N::ST)
+AVC_TI(OFF_WL, N::SK + 3, N::HT)  AVC_TI(OFF_W0T, N::HK, 2)       AVC_TI(OFF_WM0T, N::HK, N::HT) AVC_TI(OFF_WM1T, N::HK, N::HT)
+AVC_TI(OFF_WST, N::SK, N::HT)     AVC_TI(OFF_WLT, N::HK, N::ST)   AVC_TI(OFF_C0, N::HK + 1, N::HT) AVC_TI(OFF_CM0, N::HK, N::HT)
+AVC_TI(OFF_CH, N::HK, 1)          AVC_TI(OFF_C0T, N::HK, N::HT + 1) AVC_TI(OFF_CM0T, N::HK, N::HT) AVC_TI(OFF_CHT, 1, N::HT)
+
+// descriptor of the FIRST group of packed weight OFF (what the layer before it prefetches)
+template <class N, int OFF, class ST>
+__device__ __forceinline__ Next nxt(const ST&, const void* blob, const AvcOffsets& o) {
+  typedef TileInfo<N, OFF> TI;
+  Next n;
+  n.ptr = reinterpret_cast<const char*>(blob) + (long)o.v[OFF] * 2;
+  n.chunks = TI::KS * (TI::NT < ST::G ? TI::NT : ST::G);
+  return n;
+}
+__device__ __forceinline__ Next no_next() { Next n; n.ptr = nullptr; n.chunks = 0; return n; }
+
+// ---- staged, software-pipelined layer: per group one barrier + the DMA of the next group; inside a group tile t's MFMAs
+// ---- are issued before the epilogue of tile t-1, so the VALU / transcendental / store work of one tile hides under the
+// ---- matrix pipe of the next (same basic block, no barrier between).
 #define AVC_EPI(...) [&](int t, const facc& acc) __attribute__((always_inline)) { __VA_ARGS__ }
 
-template <typename V, int KS, int NT, int KSN, typename Epi>
-__device__ __forceinline__ void layer_s(Stage& st, const V* __restrict__ blob, int offw, const void* __restrict__ gnext_after,
-                                        const V (&in)[KS], Epi&& epi) {
+template <typename V, int KS, int NT, class ST, typename Epi>
+__device__ __forceinline__ void layer_s(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&in)[KS],
+                                        Epi&& epi) {
+  constexpr int G = ST::G;
+  constexpr int NG = (NT + G - 1) / G;
   facc prev;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    facc acc = (t + 1 < NT) ? tile_gemm_s<V, KS, KS>(st, gtile<V, KS>(blob, offw, t + 1), in)
-                            : tile_gemm_s<V, KS, KSN>(st, gnext_after, in);
-#ifdef AVC_NO_PIPE
-    epi(t, acc);
-#else
-    if (t > 0) epi(t - 1, prev);
-    prev = acc;
-#endif
-    __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from sinking epilogues past later tiles (spills)
+  for (int g = 0; g < NG; ++g) {
+    __syncthreads();   // group g has landed (hipcc drains vmcnt before the barrier); the other buffer is free
+    if (g + 1 < NG) {
+      Next n;
+      n.ptr = blob + (offw >> 3) + (long)((g + 1) * G * KS) * 64;
+      n.chunks = KS * ((NT - (g + 1) * G) < G ? (NT - (g + 1) * G) : G);
+      stage_issue(st, n, st.par ^ 1);
+    } else {
+      stage_issue(st, after, st.par ^ 1);
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const int t = g * G + j;
+      if (t < NT) {
+        facc acc = tile_mma<V, KS>(st, j, in);
+        if (t > 0) epi(t - 1, prev);
+        prev = acc;
+        __builtin_amdgcn_sched_barrier(0);   // keep epilogues from being sunk past later tiles
+      }
+    }
+    st.par ^= 1;
   }
-#ifndef AVC_NO_PIPE
   epi(NT - 1, prev);
   __builtin_amdgcn_sched_barrier(0);
-#endif
 }
-template <typename V, int KA, int KB, int NT, int KSN, typename Epi>
-__device__ __forceinline__ void layer2_s(Stage& st, const V* __restrict__ blob, int offw, const void* __restrict__ gnext_after,
-                                         const V (&ina)[KA], const V (&inb)[KB], Epi&& epi) {
+template <typename V, int KA, int KB, int NT, class ST, typename Epi>
+__device__ __forceinline__ void layer2_s(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&ina)[KA],
+                                         const V (&inb)[KB], Epi&& epi) {
+  constexpr int G = ST::G;
+  constexpr int KS = KA + KB;
+  constexpr int NG = (NT + G - 1) / G;
   facc prev;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    facc acc = (t + 1 < NT) ? tile_gemm2_s<V, KA, KB, KA + KB>(st, gtile<V, KA + KB>(blob, offw, t + 1), ina, inb)
-                            : tile_gemm2_s<V, KA, KB, KSN>(st, gnext_after, ina, inb);
-    if (t > 0) epi(t - 1, prev);
-    prev = acc;
-    __builtin_amdgcn_sched_barrier(0);
+  for (int g = 0; g < NG; ++g) {
+    __syncthreads();
+    if (g + 1 < NG) {
+      Next n;
+      n.ptr = blob + (offw >> 3) + (long)((g + 1) * G * KS) * 64;
+      n.chunks = KS * ((NT - (g + 1) * G) < G ? (NT - (g + 1) * G) : G);
+      stage_issue(st, n, st.par ^ 1);
+    } else {
+      stage_issue(st, after, st.par ^ 1);
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const int t = g * G + j;
+      if (t < NT) {
+        facc acc = tile_mma2<V, KA, KB>(st, j, ina, inb);
+        if (t > 0) epi(t - 1, prev);
+        prev = acc;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    st.par ^= 1;
   }
   epi(NT - 1, prev);
   __builtin_amdgcn_sched_barrier(0);
@@ -108,32 +157,32 @@ struct FwdState {
 
 // SDF trunk: layer0 .. skip layer, plus the fp32 sdf dot product (row 0 of the last layer).
 // Precondition: tile 0 of OFF_W0 has been issued (stage_issue).  gnext/KSN: the tile consumed after the trunk.
-template <class N, int KSN>
-__device__ __forceinline__ void sdf_trunk(Stage& sg, const h8* __restrict__ Wf, const float* __restrict__ T, const AvcOffsets& o,
-                                          int h, FwdState<N>& st, const void* __restrict__ gnext) {
+template <class N, class ST>
+__device__ __forceinline__ void sdf_trunk(ST& sg, const h8* __restrict__ Wf, const float* __restrict__ T, const AvcOffsets& o,
+                                          int h, FwdState<N>& st, const Next& gnext) {
   pe_compute(st.x, h, st.pe);
   pe_to_frags_f16(st.pe, st.x, h, st.pef);
-  layer_s<h8, 3, N::HT, N::HK>(sg, Wf, o.v[OFF_W0], gtile<h8, N::HK>(Wf, o.v[OFF_WM0], 0), st.pef, AVC_EPI(
+  layer_s<h8, 3, N::HT>(sg, Wf, o.v[OFF_W0], nxt<N, OFF_WM0>(sg, Wf, o), st.pef, AVC_EPI(
     float b[16], a[16];
     load16(T + o.v[OFF_B0], t, h, b);
     _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
     acc_to_frags(a, st.h1[2 * t], st.h1[2 * t + 1]);
   ));
   if constexpr (N::NMID == 2) {
-    layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM0], gtile<h8, N::HK>(Wf, o.v[OFF_WM1], 0), st.h1, AVC_EPI(
+    layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wf, o), st.h1, AVC_EPI(
       float b[16], a[16];
       load16(T + o.v[OFF_BM0], t, h, b);
       _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
       acc_to_frags(a, st.hm[0][2 * t], st.hm[0][2 * t + 1]);
     ));
-    layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM1], gtile<h8, N::HK>(Wf, o.v[OFF_WS], 0), st.hm[0], AVC_EPI(
+    layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wf, o), st.hm[0], AVC_EPI(
       float b[16], a[16];
       load16(T + o.v[OFF_BM1], t, h, b);
       _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
       acc_to_frags(a, st.hm[1][2 * t], st.hm[1][2 * t + 1]);
     ));
   } else {
-    layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM0], gtile<h8, N::HK>(Wf, o.v[OFF_WS], 0), st.h1, AVC_EPI(
+    layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wf, o), st.h1, AVC_EPI(
       float b[16], a[16];
       load16(T + o.v[OFF_BM0], t, h, b);
       _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
@@ -141,7 +190,7 @@ __device__ __forceinline__ void sdf_trunk(Stage& sg, const h8* __restrict__ Wf, 
     ));
   }
   float part = 0.f;
-  layer_s<h8, N::HK, N::ST, KSN>(sg, Wf, o.v[OFF_WS], gnext, st.hm[N::NMID - 1], AVC_EPI(
+  layer_s<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], gnext, st.hm[N::NMID - 1], AVC_EPI(
     float b[16], a[16];
     load16(T + o.v[OFF_BS], t, h, b);
     _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
@@ -159,8 +208,8 @@ __device__ __forceinline__ void sdf_trunk(Stage& sg, const h8* __restrict__ Wf, 
 
 // SDF value only (avc_sdf_forward): same layers as sdf_trunk but every activation array dies as soon as the next layer
 // has consumed it, which keeps the kernel at two wavefronts per SIMD.
-template <class N>
-__device__ __forceinline__ float sdf_only(Stage& sg, const h8* __restrict__ Wf, const float* __restrict__ T, const AvcOffsets& o,
+template <class N, class ST>
+__device__ __forceinline__ float sdf_only(ST& sg, const h8* __restrict__ Wf, const float* __restrict__ T, const AvcOffsets& o,
                                           int h, const float (&x)[3]) {
   PE pe;
   pe_compute(x, h, pe);
@@ -176,7 +225,7 @@ __device__ __forceinline__ float sdf_only(Stage& sg, const h8* __restrict__ Wf, 
     {
       h8 pef[3];
       pe_to_frags_f16(pe, x, h, pef);
-      layer_s<h8, 3, N::HT, N::HK>(sg, Wf, o.v[OFF_W0], gtile<h8, N::HK>(Wf, o.v[OFF_WM0], 0), pef, AVC_EPI(
+      layer_s<h8, 3, N::HT>(sg, Wf, o.v[OFF_W0], nxt<N, OFF_WM0>(sg, Wf, o), pef, AVC_EPI(
         float b[16], a[16];
         load16(T + o.v[OFF_B0], t, h, b);
         _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
@@ -185,20 +234,20 @@ __device__ __forceinline__ float sdf_only(Stage& sg, const h8* __restrict__ Wf, 
     }
     if constexpr (N::NMID == 2) {
       h8 hm0[N::HK];
-      layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM0], gtile<h8, N::HK>(Wf, o.v[OFF_WM1], 0), h1, AVC_EPI(
+      layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wf, o), h1, AVC_EPI(
         float b[16], a[16];
         load16(T + o.v[OFF_BM0], t, h, b);
         _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
         acc_to_frags(a, hm0[2 * t], hm0[2 * t + 1]);
       ));
-      layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM1], gtile<h8, N::HK>(Wf, o.v[OFF_WS], 0), hm0, AVC_EPI(
+      layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wf, o), hm0, AVC_EPI(
         float b[16], a[16];
         load16(T + o.v[OFF_BM1], t, h, b);
         _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
         acc_to_frags(a, hlast[2 * t], hlast[2 * t + 1]);
       ));
     } else {
-      layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM0], gtile<h8, N::HK>(Wf, o.v[OFF_WS], 0), h1, AVC_EPI(
+      layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wf, o), h1, AVC_EPI(
         float b[16], a[16];
         load16(T + o.v[OFF_BM0], t, h, b);
         _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
@@ -206,7 +255,7 @@ __device__ __forceinline__ float sdf_only(Stage& sg, const h8* __restrict__ Wf, 
       ));
     }
   }
-  layer_s<h8, N::HK, N::ST, 1>(sg, Wf, o.v[OFF_WS], (const h8*)nullptr, hlast, AVC_EPI(
+  layer_s<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], no_next(), hlast, AVC_EPI(
     float b[16], w[16];
     load16(T + o.v[OFF_BS], t, h, b);
     load16(T + o.v[OFF_WL0_ACC], t, h, w);
@@ -216,10 +265,10 @@ __device__ __forceinline__ float sdf_only(Stage& sg, const h8* __restrict__ Wf, 
 }
 
 // feature = rows 1..H of the last layer (u = [h_skip ; pe]/sqrt2 folded into the packed weights)
-template <class N, int KSN>
-__device__ __forceinline__ void sdf_feature(Stage& sg, const h8* __restrict__ Wf, const float* __restrict__ T, const AvcOffsets& o,
-                                            int h, const FwdState<N>& st, h8 (&feat)[N::HK], const void* __restrict__ gnext) {
-  layer2_s<h8, N::SK, 3, N::HT, KSN>(sg, Wf, o.v[OFF_WL], gnext, st.hs, st.pef, AVC_EPI(
+template <class N, class ST>
+__device__ __forceinline__ void sdf_feature(ST& sg, const h8* __restrict__ Wf, const float* __restrict__ T, const AvcOffsets& o,
+                                            int h, const FwdState<N>& st, h8 (&feat)[N::HK], const Next& gnext) {
+  layer2_s<h8, N::SK, 3, N::HT>(sg, Wf, o.v[OFF_WL], gnext, st.hs, st.pef, AVC_EPI(
     float b[16], a[16];
     load16(T + o.v[OFF_BL], t, h, b);
     _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = acc[r] + b[r];
@@ -228,9 +277,9 @@ __device__ __forceinline__ void sdf_feature(Stage& sg, const h8* __restrict__ Wf
 }
 
 // Normal n = d sdf / d x by the reverse sweep.
-template <class N, int KSN>
-__device__ __forceinline__ void sdf_normal(Stage& sg, const h8* __restrict__ Wf, const float* __restrict__ T, const AvcOffsets& o,
-                                           int h, const FwdState<N>& st, float (&n)[3], const void* __restrict__ gnext) {
+template <class N, class ST>
+__device__ __forceinline__ void sdf_normal(ST& sg, const h8* __restrict__ Wf, const float* __restrict__ T, const AvcOffsets& o,
+                                           int h, const FwdState<N>& st, float (&n)[3], const Next& gnext) {
   float w8[8];
   h8 g_in_s[N::SK];
 #pragma unroll
@@ -240,7 +289,7 @@ __device__ __forceinline__ void sdf_normal(Stage& sg, const h8* __restrict__ Wf,
     for (int j = 0; j < 8; ++j) g_in_s[s][j] = (_Float16)(w8[j] * sig_from_h((float)st.hs[s][j]));
   }
   h8 g[N::HK];
-  layer_s<h8, N::SK, N::HT, N::HK>(sg, Wf, o.v[OFF_WST], gtile<h8, N::HK>(Wf, N::NMID == 2 ? o.v[OFF_WM1T] : o.v[OFF_WM0T], 0),
+  layer_s<h8, N::SK, N::HT>(sg, Wf, o.v[OFF_WST], (N::NMID == 2 ? nxt<N, OFF_WM1T>(sg, Wf, o) : nxt<N, OFF_WM0T>(sg, Wf, o)),
                                    g_in_s, AVC_EPI(
     _Pragma("unroll") for (int j = 0; j < 8; ++j) {
       g[2 * t][j] = (_Float16)(acc[j] * sig_from_h((float)st.hm[N::NMID - 1][2 * t][j]));
@@ -250,14 +299,14 @@ __device__ __forceinline__ void sdf_normal(Stage& sg, const h8* __restrict__ Wf,
   ));
   h8 g2[N::HK];
   if constexpr (N::NMID == 2) {
-    layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM1T], gtile<h8, N::HK>(Wf, o.v[OFF_WM0T], 0), g, AVC_EPI(
+    layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1T], nxt<N, OFF_WM0T>(sg, Wf, o), g, AVC_EPI(
       _Pragma("unroll") for (int j = 0; j < 8; ++j) {
         g2[2 * t][j] = (_Float16)(acc[j] * sig_from_h((float)st.hm[0][2 * t][j]));
         g2[2 * t + 1][j] = (_Float16)(acc[8 + j] * sig_from_h((float)st.hm[0][2 * t + 1][j]));
       }
       pin2(g2[2 * t], g2[2 * t + 1]);
     ));
-    layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM0T], gtile<h8, N::HK>(Wf, o.v[OFF_W0T], 0), g2, AVC_EPI(
+    layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0T], nxt<N, OFF_W0T>(sg, Wf, o), g2, AVC_EPI(
       _Pragma("unroll") for (int j = 0; j < 8; ++j) {
         g[2 * t][j] = (_Float16)(acc[j] * sig_from_h((float)st.h1[2 * t][j]));
         g[2 * t + 1][j] = (_Float16)(acc[8 + j] * sig_from_h((float)st.h1[2 * t + 1][j]));
@@ -265,7 +314,7 @@ __device__ __forceinline__ void sdf_normal(Stage& sg, const h8* __restrict__ Wf,
       pin2(g[2 * t], g[2 * t + 1]);
     ));
   } else {
-    layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM0T], gtile<h8, N::HK>(Wf, o.v[OFF_W0T], 0), g, AVC_EPI(
+    layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0T], nxt<N, OFF_W0T>(sg, Wf, o), g, AVC_EPI(
       _Pragma("unroll") for (int j = 0; j < 8; ++j) {
         g2[2 * t][j] = (_Float16)(acc[j] * sig_from_h((float)st.h1[2 * t][j]));
         g2[2 * t + 1][j] = (_Float16)(acc[8 + j] * sig_from_h((float)st.h1[2 * t + 1][j]));
@@ -277,7 +326,7 @@ __device__ __forceinline__ void sdf_normal(Stage& sg, const h8* __restrict__ Wf,
   }
   float part[3] = {0.f, 0.f, 0.f};
   const float* wpe = T + o.v[OFF_WL0_PE] + h * 24;
-  layer_s<h8, N::HK, 2, KSN>(sg, Wf, o.v[OFF_W0T], gnext, g, AVC_EPI(
+  layer_s<h8, N::HK, 2>(sg, Wf, o.v[OFF_W0T], gnext, g, AVC_EPI(
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {
       const int q = 16 * t + r;
       if (q < 24) part[q % 3] += st.pe.d[q] * (acc[r] + wpe[q]);
@@ -288,8 +337,8 @@ __device__ __forceinline__ void sdf_normal(Stage& sg, const h8* __restrict__ Wf,
 }
 
 // colour MLP: r0 = [x, n, feature] -> ... -> sigmoid([rgb_prior ; rgb_clip])  (6 outputs: half 0 holds 0..3, half 1 holds 4,5)
-template <class N>
-__device__ __forceinline__ void color_forward(Stage& sg, const h8* __restrict__ Wf, const float* __restrict__ T, const AvcOffsets& o,
+template <class N, class ST>
+__device__ __forceinline__ void color_forward(ST& sg, const h8* __restrict__ Wf, const float* __restrict__ T, const AvcOffsets& o,
                                               int h, const float (&x)[3], const float (&n)[3], const h8 (&feat)[N::HK],
                                               float (&rgb)[4]) {
   h8 xn[1];
@@ -300,7 +349,7 @@ __device__ __forceinline__ void color_forward(Stage& sg, const h8* __restrict__ 
     for (int c = 0; c < 3; ++c) { xn[0][c] = (_Float16)x[c]; xn[0][3 + c] = (_Float16)n[c]; }
   }
   h8 r1[N::HK];
-  layer2_s<h8, N::HK, 1, N::HT, N::HK>(sg, Wf, o.v[OFF_C0], gtile<h8, N::HK>(Wf, N::NCMID == 1 ? o.v[OFF_CM0] : o.v[OFF_CH], 0),
+  layer2_s<h8, N::HK, 1, N::HT>(sg, Wf, o.v[OFF_C0], (N::NCMID == 1 ? nxt<N, OFF_CM0>(sg, Wf, o) : nxt<N, OFF_CH>(sg, Wf, o)),
                                        feat, xn, AVC_EPI(
     float b[16], a[16];
     load16(T + o.v[OFF_CB0], t, h, b);
@@ -309,7 +358,7 @@ __device__ __forceinline__ void color_forward(Stage& sg, const h8* __restrict__ 
   ));
   h8 r2[N::HK];
   if constexpr (N::NCMID == 1) {
-    layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_CM0], gtile<h8, N::HK>(Wf, o.v[OFF_CH], 0), r1, AVC_EPI(
+    layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_CM0], nxt<N, OFF_CH>(sg, Wf, o), r1, AVC_EPI(
       float b[16], a[16];
       load16(T + o.v[OFF_CBM0], t, h, b);
       _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r] + b[r], 0.f);
@@ -319,7 +368,7 @@ __device__ __forceinline__ void color_forward(Stage& sg, const h8* __restrict__ 
 #pragma unroll
     for (int s = 0; s < N::HK; ++s) r2[s] = r1[s];
   }
-  layer_s<h8, N::HK, 1, 1>(sg, Wf, o.v[OFF_CH], (const h8*)nullptr, r2, AVC_EPI(
+  layer_s<h8, N::HK, 1>(sg, Wf, o.v[OFF_CH], no_next(), r2, AVC_EPI(
     float b[16];
     load16(T + o.v[OFF_CBH], 0, h, b);
     _Pragma("unroll") for (int r = 0; r < 4; ++r) rgb[r] = sigmoidf_(acc[r] + b[r]);

@@ -12,6 +12,12 @@
 // Activations that a later phase needs again are parked in a per-wavefront scratch slot (frag layout, L2/MALL
 // resident because the slot is reused for every block the wave processes).
 #include "avc_mlp.h"
+#ifndef BWD_WAVES_PER_EU
+#define BWD_WAVES_PER_EU 2   // 2 waves/SIMD (256 VGPRs): measured 20 % faster than 1 wave x 512 registers
+#endif
+#ifndef BWD_G
+#define BWD_G 2   // tiles per staged group (LDS = 2 * G * 17 KiB = 68 KiB per workgroup -> 2 workgroups per CU)
+#endif
 #include "../../include/avc.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -57,7 +63,9 @@ struct BwdLayout {
   static constexpr int S_APM = S_AP1 + N::HK;
   static constexpr int S_R1 = S_APM + NM * N::HK;
   static constexpr int S_R2 = S_R1 + N::HK;
-  static constexpr int S_KSTEPS = S_R2 + NC * N::HK;
+  static constexpr int S_DFEAT = S_R2 + NC * N::HK;   // ybar[1:] (bf16), parked between phases D and F
+  static constexpr int S_APS = S_DFEAT + N::HK;        // abar'_s (bf16), parked between phases E and F
+  static constexpr int S_KSTEPS = S_APS + N::SK;
 };
 
 extern "C" int avc_bwd_panel_tiles(int net) {
@@ -108,8 +116,8 @@ __device__ __forceinline__ V zero_frag() {
   return z;
 }
 
-template <typename V> __device__ __forceinline__ void scr_store(V* scr, int ks, int lane, const V& v) { scr[ks * 64 + lane] = v; }
-template <typename V> __device__ __forceinline__ V scr_load(const V* scr, int ks, int lane) { return scr[ks * 64 + lane]; }
+template <typename V> __device__ __forceinline__ void scr_store(V* scr, int ks, int, const V& v) { scr[ks * 64] = v; }
+template <typename V> __device__ __forceinline__ V scr_load(const V* scr, int ks, int) { return scr[ks * 64]; }
 
 // All phases run on the staged engine (avc_stage.h / layer_s): every weight tile is copied once per workgroup into
 // LDS, the epilogue of tile t-1 (activation, panel transposition, scratch parking) is issued under the MFMAs of tile t.
@@ -134,30 +142,35 @@ __device__ __forceinline__ void pstore(b8* __restrict__ panel_blk, bool live, in
 }
 
 template <class N>
-__global__ __launch_bounds__(256) void mlp_bwd_kernel(PointSrc ps, long npts, const h8* __restrict__ Wf0,
+__global__ __launch_bounds__(256, BWD_WAVES_PER_EU) void mlp_bwd_kernel(PointSrc ps, long npts, const h8* __restrict__ Wf0,
                                                       const b8* __restrict__ Wb0, const float* __restrict__ T0, AvcOffsets o,
                                                       const float* __restrict__ d_sdf, const float* __restrict__ d_normal,
                                                       const float* __restrict__ d_rgb, b8* __restrict__ panels,
                                                       char* __restrict__ scratch) {
   typedef BwdLayout<N> L;
-  __shared__ __attribute__((aligned(16))) char lds[STAGE_LDS_BYTES];
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  typedef StageT<BWD_G> ST;
   const int lane = threadIdx.x & 63, h = lane >> 5, p = lane & 31;
   const int wv = threadIdx.x >> 6;
   const long nblk = (npts + 31) >> 5;
   const long wslot = (long)blockIdx.x * 4 + wv;
-  h8* scr = reinterpret_cast<h8*>(scratch + wslot * (long)L::S_KSTEPS * 64 * 16);
-  b8* scrb = reinterpret_cast<b8*>(scr);
+  char* scr0 = scratch + wslot * (long)L::S_KSTEPS * 64 * 16 + lane * 16;   // this lane's 16-B column of the wave's slot
   h8 e0h, e1h; b8 e0b, e1b;
   make_sel<h8>(lane, e0h, e1h);
   make_sel<b8>(lane, e0b, e1b);
-  Stage sg = stage_init(lds);
-  stage_issue<h8, 3>(sg, gtile<h8, 3>(Wf0, o.v[OFF_W0], 0), 0);
+  ST sg = stage_init<BWD_G>(lds);
+  stage_issue(sg, nxt<N, OFF_W0>(sg, Wf0, o), 0);
 
   // every wavefront of a workgroup runs the same number of iterations (workgroup-uniform loop bound)
   for (long blk0 = (long)blockIdx.x * 4; blk0 < nblk; blk0 += (long)gridDim.x * 4) {
     const h8* Wf = launder(Wf0);
     const b8* Wb = launder(Wb0);
     const float* T = launder(T0);
+    // opaque per iteration as well: otherwise every scratch address of the ~400 accesses is hoisted out of the loop
+    // as a loop invariant and spilled (measured: 269 spill stores in the prologue)
+    asm volatile("" : "+v"(scr0));
+    h8* scr = reinterpret_cast<h8*>(scr0);
+    b8* scrb = reinterpret_cast<b8*>(scr0);
     const long blk = blk0 + wv;
     const bool live = blk < nblk;
     b8* pblk = panels + (live ? blk : 0) * (long)L::P_TILES * 128;
@@ -175,8 +188,11 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PointSrc ps, long npts, co
     pe_to_frags_f16(pe, x, h, pef);
     pstore<h8>(pblk, live, L::P_H0, lane, pef[0], pef[1], e0h, e1h);
     pstore<h8>(pblk, live, L::P_H0 + 1, lane, pef[2], zero_frag<h8>(), e0h, e1h);
-    h8 hs[N::SK];
+    // Register discipline: nothing but x, n, nbar, d_sdf survives a phase.  Every activation is parked in the wave's
+    // scratch slot (L2 resident) and re-loaded / re-computed (positional encoding) where it is needed again; this keeps
+    // each phase at "input + output + accumulators" and leaves registers for pipelining the LDS operand reads.
     {
+      h8 hs[N::SK];
 #define AVC_FWD_KEEP(OFFB, OUT, SCR, PT)                                                     \
   AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
           _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);  \
@@ -184,21 +200,21 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PointSrc ps, long npts, co
           scr_store(scr, (SCR) + 2 * t, lane, OUT[2 * t]); scr_store(scr, (SCR) + 2 * t + 1, lane, OUT[2 * t + 1]); \
           pstore<h8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0h, e1h);)
       h8 h1[N::HK];
-      layer_s<h8, 3, N::HT, N::HK>(sg, Wf, o.v[OFF_W0], gtile<h8, N::HK>(Wf, o.v[OFF_WM0], 0), pef,
+      layer_s<h8, 3, N::HT>(sg, Wf, o.v[OFF_W0], nxt<N, OFF_WM0>(sg, Wf, o), pef,
                                    AVC_FWD_KEEP(OFF_B0, h1, L::S_H1, L::P_H1));
       h8 hm0[N::HK];
       if constexpr (N::NMID == 2) {
-        layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM0], gtile<h8, N::HK>(Wf, o.v[OFF_WM1], 0), h1,
+        layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wf, o), h1,
                                          AVC_FWD_KEEP(OFF_BM0, hm0, L::S_HM, L::P_HM));
         h8 hm1[N::HK];
-        layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM1], gtile<h8, N::HK>(Wf, o.v[OFF_WS], 0), hm0,
+        layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wf, o), hm0,
                                          AVC_FWD_KEEP(OFF_BM1, hm1, L::S_HM + N::HK, L::P_HM + N::HT));
-        layer_s<h8, N::HK, N::ST, N::SK>(sg, Wf, o.v[OFF_WS], gtile<h8, N::SK>(Wf, o.v[OFF_WST], 0), hm1,
+        layer_s<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], nxt<N, OFF_WST>(sg, Wf, o), hm1,
                                          AVC_FWD_KEEP(OFF_BS, hs, L::S_HS, L::P_HS));
       } else {
-        layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM0], gtile<h8, N::HK>(Wf, o.v[OFF_WS], 0), h1,
+        layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wf, o), h1,
                                          AVC_FWD_KEEP(OFF_BM0, hm0, L::S_HM, L::P_HM));
-        layer_s<h8, N::HK, N::ST, N::SK>(sg, Wf, o.v[OFF_WS], gtile<h8, N::SK>(Wf, o.v[OFF_WST], 0), hm0,
+        layer_s<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], nxt<N, OFF_WST>(sg, Wf, o), hm0,
                                          AVC_FWD_KEEP(OFF_BS, hs, L::S_HS, L::P_HS));
       }
     }
@@ -210,10 +226,11 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PointSrc ps, long npts, co
 #pragma unroll
       for (int s = 0; s < N::SK; ++s) {
         load8(T + o.v[OFF_WL0_FRAG], s, h, w8);
+        const h8 hsv = scr_load(scr, L::S_HS + s, lane);
         h8 q;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float sg_ = sig_from_h((float)hs[s][j]);
+          const float sg_ = sig_from_h((float)hsv[j]);
           g_s[s][j] = (_Float16)(w8[j] * sg_);
           q[j] = (_Float16)(w8[j] * AVC_BETA * sg_ * (1.f - sg_) * (1.f / 64.f));
         }
@@ -236,24 +253,26 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PointSrc ps, long npts, co
       h8 g[N::HK];
       h8 g2[N::HK];
       if constexpr (N::NMID == 2) {
-        layer_s<h8, N::SK, N::HT, N::HK>(sg, Wf, o.v[OFF_WST], gtile<h8, N::HK>(Wf, o.v[OFF_WM1T], 0), g_s,
+        layer_s<h8, N::SK, N::HT>(sg, Wf, o.v[OFF_WST], nxt<N, OFF_WM1T>(sg, Wf, o), g_s,
                                          AVC_NSTEP(g, L::S_HM + N::HK, L::S_QM + N::HK, L::P_GAM + N::HT));
-        layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM1T], gtile<h8, N::HK>(Wf, o.v[OFF_WM0T], 0), g,
+        layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1T], nxt<N, OFF_WM0T>(sg, Wf, o), g,
                                          AVC_NSTEP(g2, L::S_HM, L::S_QM, L::P_GAM));
-        layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM0T], gtile<h8, N::HK>(Wf, o.v[OFF_W0T], 0), g2,
+        layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0T], nxt<N, OFF_W0T>(sg, Wf, o), g2,
                                          AVC_NSTEP(g, L::S_H1, L::S_Q1, L::P_GA1));
       } else {
-        layer_s<h8, N::SK, N::HT, N::HK>(sg, Wf, o.v[OFF_WST], gtile<h8, N::HK>(Wf, o.v[OFF_WM0T], 0), g_s,
+        layer_s<h8, N::SK, N::HT>(sg, Wf, o.v[OFF_WST], nxt<N, OFF_WM0T>(sg, Wf, o), g_s,
                                          AVC_NSTEP(g2, L::S_HM, L::S_QM, L::P_GAM));
-        layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_WM0T], gtile<h8, N::HK>(Wf, o.v[OFF_W0T], 0), g2,
+        layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0T], nxt<N, OFF_W0T>(sg, Wf, o), g2,
                                          AVC_NSTEP(g, L::S_H1, L::S_Q1, L::P_GA1));
       }
       float part[3] = {0.f, 0.f, 0.f};
       const float* wpe = T + o.v[OFF_WL0_PE] + h * 24;
-      layer_s<h8, N::HK, 2, N::SK + 3>(sg, Wf, o.v[OFF_W0T], gtile<h8, N::SK + 3>(Wf, o.v[OFF_WL], 0), g, AVC_EPI(
+      PE pe2;
+      pe_compute(x, h, pe2);
+      layer_s<h8, N::HK, 2>(sg, Wf, o.v[OFF_W0T], nxt<N, OFF_WL>(sg, Wf, o), g, AVC_EPI(
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {
           const int q = 16 * t + r;
-          if (q < 24) part[q % 3] += pe.d[q] * (acc[r] + wpe[q]);
+          if (q < 24) part[q % 3] += pe2.d[q] * (acc[r] + wpe[q]);
         }
       ));
 #pragma unroll
@@ -263,13 +282,22 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PointSrc ps, long npts, co
     float delta_o[4];   // half 0: outputs 0..3, half 1: outputs 4,5 (delta = d_rgb * rgb (1-rgb))
     {
       h8 feat[N::HK];
-      layer2_s<h8, N::SK, 3, N::HT, N::HK + 1>(sg, Wf, o.v[OFF_WL], gtile<h8, N::HK + 1>(Wf, o.v[OFF_C0], 0), hs, pef, AVC_EPI(
+      {
+        h8 hs[N::SK];
+#pragma unroll
+        for (int s = 0; s < N::SK; ++s) hs[s] = scr_load(scr, L::S_HS + s, lane);
+        PE pe3;
+        pe_compute(x, h, pe3);
+        h8 pef3[3];
+        pe_to_frags_f16(pe3, x, h, pef3);
+        layer2_s<h8, N::SK, 3, N::HT>(sg, Wf, o.v[OFF_WL], nxt<N, OFF_C0>(sg, Wf, o), hs, pef3, AVC_EPI(
         float b[16], a[16];
         load16(T + o.v[OFF_BL], t, h, b);
         _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = acc[r] + b[r];
         acc_to_frags(a, feat[2 * t], feat[2 * t + 1]);
         pstore<h8>(pblk, live, L::P_FEAT + t, lane, feat[2 * t], feat[2 * t + 1], e0h, e1h);
-      ));
+        ));
+      }
       h8 xn[1];
       xn[0] = zero_frag<h8>();
       if (h == 0) {
@@ -286,17 +314,17 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PointSrc ps, long npts, co
       h8 r1[N::HK];
       h8 r2[N::HK];
       if constexpr (N::NCMID == 1) {
-        layer2_s<h8, N::HK, 1, N::HT, N::HK>(sg, Wf, o.v[OFF_C0], gtile<h8, N::HK>(Wf, o.v[OFF_CM0], 0), feat, xn,
+        layer2_s<h8, N::HK, 1, N::HT>(sg, Wf, o.v[OFF_C0], nxt<N, OFF_CM0>(sg, Wf, o), feat, xn,
                                              AVC_RELU_KEEP(OFF_CB0, r1, L::S_R1, L::P_R1));
-        layer_s<h8, N::HK, N::HT, N::HK>(sg, Wf, o.v[OFF_CM0], gtile<h8, N::HK>(Wf, o.v[OFF_CH], 0), r1,
+        layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_CM0], nxt<N, OFF_CH>(sg, Wf, o), r1,
                                          AVC_RELU_KEEP(OFF_CBM0, r2, L::S_R2, L::P_R2));
       } else {
-        layer2_s<h8, N::HK, 1, N::HT, N::HK>(sg, Wf, o.v[OFF_C0], gtile<h8, N::HK>(Wf, o.v[OFF_CH], 0), feat, xn,
+        layer2_s<h8, N::HK, 1, N::HT>(sg, Wf, o.v[OFF_C0], nxt<N, OFF_CH>(sg, Wf, o), feat, xn,
                                              AVC_RELU_KEEP(OFF_CB0, r1, L::S_R1, L::P_R1));
 #pragma unroll
         for (int s = 0; s < N::HK; ++s) r2[s] = r1[s];
       }
-      layer_s<h8, N::HK, 1, 1>(sg, Wf, o.v[OFF_CH], gtile<b8, 1>(Wb, o.v[OFF_CHT], 0), r2, AVC_EPI(
+      layer_s<h8, N::HK, 1>(sg, Wf, o.v[OFF_CH], nxt<N, OFF_CHT>(sg, Wb, o), r2, AVC_EPI(
         float b[16];
         load16(T + o.v[OFF_CBH], 0, h, b);
         _Pragma("unroll") for (int r = 0; r < 4; ++r) {
@@ -309,8 +337,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PointSrc ps, long npts, co
     }
     // ------------------------------------------------------------------ phase D: colour backward (bf16)
     float nbar[3];
-    b8 dfeat[N::HK];
     {
+      b8 dfeat[N::HK];
       b8 dof[1];
       dof[0] = zero_frag<b8>();
 #pragma unroll
@@ -326,23 +354,25 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PointSrc ps, long npts, co
       b8 dl[N::HK];
       b8 d1[N::HK];
       if constexpr (N::NCMID == 1) {
-        layer_s<b8, 1, N::HT, N::HK>(sg, Wb, o.v[OFF_CHT], gtile<b8, N::HK>(Wb, o.v[OFF_CM0T], 0), dof,
+        layer_s<b8, 1, N::HT>(sg, Wb, o.v[OFF_CHT], nxt<N, OFF_CM0T>(sg, Wb, o), dof,
                                      AVC_RELU_BWD(dl, L::S_R2, L::P_D2));
-        layer_s<b8, N::HK, N::HT, N::HK>(sg, Wb, o.v[OFF_CM0T], gtile<b8, N::HK>(Wb, o.v[OFF_C0T], 0), dl,
+        layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_CM0T], nxt<N, OFF_C0T>(sg, Wb, o), dl,
                                          AVC_RELU_BWD(d1, L::S_R1, L::P_D1));
       } else {
-        layer_s<b8, 1, N::HT, N::HK>(sg, Wb, o.v[OFF_CHT], gtile<b8, N::HK>(Wb, o.v[OFF_C0T], 0), dof,
+        layer_s<b8, 1, N::HT>(sg, Wb, o.v[OFF_CHT], nxt<N, OFF_C0T>(sg, Wb, o), dof,
                                      AVC_RELU_BWD(d1, L::S_R1, L::P_D1));
       }
       // d r0 = C0^T delta1: HT feature tiles, then the [x,n] tile (rows 3,4,5 = d n)
       float dn_acc[3] = {0.f, 0.f, 0.f};
-      layer_s<b8, N::HK, N::HT + 1, 3>(sg, Wb, o.v[OFF_C0T], gtile<b8, 3>(Wb, o.v[OFF_W0], 0), d1, AVC_EPI(
+      layer_s<b8, N::HK, N::HT + 1>(sg, Wb, o.v[OFF_C0T], nxt<N, OFF_W0>(sg, Wb, o), d1, AVC_EPI(
         if (t < N::HT) {
           _Pragma("unroll") for (int j = 0; j < 8; ++j) {
             dfeat[2 * (t < N::HT ? t : 0)][j] = (__bf16)acc[j];
             dfeat[2 * (t < N::HT ? t : 0) + 1][j] = (__bf16)acc[8 + j];
           }
           pin2(dfeat[2 * (t < N::HT ? t : 0)], dfeat[2 * (t < N::HT ? t : 0) + 1]);
+          scr_store(scrb, L::S_DFEAT + 2 * (t < N::HT ? t : 0), lane, dfeat[2 * (t < N::HT ? t : 0)]);
+          scr_store(scrb, L::S_DFEAT + 2 * (t < N::HT ? t : 0) + 1, lane, dfeat[2 * (t < N::HT ? t : 0) + 1]);
           pstore<b8>(pblk, live, L::P_DFEAT + t, lane, dfeat[2 * (t < N::HT ? t : 0)], dfeat[2 * (t < N::HT ? t : 0) + 1], e0b, e1b);
         } else {
           dn_acc[0] = acc[3]; dn_acc[1] = acc[0]; dn_acc[2] = acc[1];
@@ -375,11 +405,14 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PointSrc ps, long npts, co
       b8* dd2 = pblk + (long)L::P_ONE * 128 + lane; dd2[0] = o0; dd2[64] = o1;
     }
     // ------------------------------------------------------------------ phase E: second-order sweep (i) (bf16)
-    b8 aps[N::SK];   // abar'_s stays in registers into phase F
     {
       b8 gb0[3];
+      {
+        PE pe4;
+        pe_compute(x, h, pe4);
 #pragma unroll
-      for (int q = 0; q < 24; ++q) gb0[q >> 3][q & 7] = (__bf16)(pe.d[q] * nbar[q % 3]);
+        for (int q = 0; q < 24; ++q) gb0[q >> 3][q & 7] = (__bf16)(pe4.d[q] * nbar[q % 3]);
+      }
       pstore<b8>(pblk, live, L::P_GB0, lane, gb0[0], gb0[1], e0b, e1b);
       pstore<b8>(pblk, live, L::P_GB0 + 1, lane, gb0[2], zero_frag<b8>(), e0b, e1b);
       // gbar_a = W gbar_h(in); abar' = gbar_a * q * 64 ; gbar_h(out) = gbar_a * sigma(h_out)
@@ -392,40 +425,43 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PointSrc ps, long npts, co
             OUT[2 * t + 1][j] = (__bf16)(acc[8 + j] * sig_from_h((float)hv1[j]));                            \
             a0[j] = (__bf16)(acc[j] * (float)q0[j] * 64.f); a1[j] = (__bf16)(acc[8 + j] * (float)q1[j] * 64.f); } \
           pin2(OUT[2 * t], OUT[2 * t + 1]);                                                                  \
-          if (KEEP) { aps[2 * (KEEP ? t : 0)] = a0; aps[2 * (KEEP ? t : 0) + 1] = a1; }                      \
-          else { scr_store(scrb, (SAP) + 2 * t, lane, a0); scr_store(scrb, (SAP) + 2 * t + 1, lane, a1); }   \
+          scr_store(scrb, (SAP) + 2 * t, lane, a0); scr_store(scrb, (SAP) + 2 * t + 1, lane, a1);           \
           pstore<b8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0b, e1b);)
       b8 gb1[N::HK];
-      layer_s<b8, 3, N::HT, N::HK>(sg, Wb, o.v[OFF_W0], gtile<b8, N::HK>(Wb, o.v[OFF_WM0], 0), gb0,
+      layer_s<b8, 3, N::HT>(sg, Wb, o.v[OFF_W0], nxt<N, OFF_WM0>(sg, Wb, o), gb0,
                                    AVC_SECOND(gb1, L::S_H1, L::S_Q1, L::S_AP1, L::P_GBH1, false));
       b8 gbm[N::HK];
       b8 gbs[N::SK];
       if constexpr (N::NMID == 2) {
-        layer_s<b8, N::HK, N::HT, N::HK>(sg, Wb, o.v[OFF_WM0], gtile<b8, N::HK>(Wb, o.v[OFF_WM1], 0), gb1,
+        layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wb, o), gb1,
                                          AVC_SECOND(gbm, L::S_HM, L::S_QM, L::S_APM, L::P_GBHM, false));
         b8 gbm1[N::HK];
-        layer_s<b8, N::HK, N::HT, N::HK>(sg, Wb, o.v[OFF_WM1], gtile<b8, N::HK>(Wb, o.v[OFF_WS], 0), gbm,
+        layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wb, o), gbm,
                                          AVC_SECOND(gbm1, L::S_HM + N::HK, L::S_QM + N::HK, L::S_APM + N::HK, L::P_GBHM + N::HT, false));
-        layer_s<b8, N::HK, N::ST, N::HK>(sg, Wb, o.v[OFF_WS], gtile<b8, N::HK>(Wb, o.v[OFF_WLT], 0), gbm1,
-                                         AVC_SECOND(gbs, L::S_HS, L::S_QS, 0, L::P_GBHS, true));
+        layer_s<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WS], nxt<N, OFF_WLT>(sg, Wb, o), gbm1,
+                                         AVC_SECOND(gbs, L::S_HS, L::S_QS, L::S_APS, L::P_GBHS, true));
       } else {
-        layer_s<b8, N::HK, N::HT, N::HK>(sg, Wb, o.v[OFF_WM0], gtile<b8, N::HK>(Wb, o.v[OFF_WS], 0), gb1,
+        layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wb, o), gb1,
                                          AVC_SECOND(gbm, L::S_HM, L::S_QM, L::S_APM, L::P_GBHM, false));
-        layer_s<b8, N::HK, N::ST, N::HK>(sg, Wb, o.v[OFF_WS], gtile<b8, N::HK>(Wb, o.v[OFF_WLT], 0), gbm,
-                                         AVC_SECOND(gbs, L::S_HS, L::S_QS, 0, L::P_GBHS, true));
+        layer_s<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WS], nxt<N, OFF_WLT>(sg, Wb, o), gbm,
+                                         AVC_SECOND(gbs, L::S_HS, L::S_QS, L::S_APS, L::P_GBHS, true));
       }
     }
     // ------------------------------------------------------------------ phase F: reverse sweep (ii) (bf16)
     {
       b8 as_[N::SK];
+      b8 dfeat[N::HK];
+#pragma unroll
+      for (int s = 0; s < N::HK; ++s) dfeat[s] = scr_load(scrb, L::S_DFEAT + s, lane);
       // ubar[:SKIP]/sqrt2 = (W_last[1:,:]^T dfeat + W_last[0,:] d_sdf)/sqrt2 ; 1/sqrt2 is folded into both packs
-      layer_s<b8, N::HK, N::ST, N::SK>(sg, Wb, o.v[OFF_WLT], gtile<b8, N::SK>(Wb, o.v[OFF_WST], 0), dfeat, AVC_EPI(
+      layer_s<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WLT], nxt<N, OFF_WST>(sg, Wb, o), dfeat, AVC_EPI(
         float wa[16];
         load16(T + o.v[OFF_WL0_ACC], t, h, wa);
         const h8 hv0 = scr_load(scr, L::S_HS + 2 * t, lane), hv1 = scr_load(scr, L::S_HS + 2 * t + 1, lane);
+        const b8 ap0 = scr_load(scrb, L::S_APS + 2 * t, lane), ap1 = scr_load(scrb, L::S_APS + 2 * t + 1, lane);
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {
-          as_[2 * t][j] = (__bf16)((float)aps[2 * t][j] + (acc[j] + wa[j] * dsdf) * sig_from_h((float)hv0[j]));
-          as_[2 * t + 1][j] = (__bf16)((float)aps[2 * t + 1][j] + (acc[8 + j] + wa[8 + j] * dsdf) * sig_from_h((float)hv1[j]));
+          as_[2 * t][j] = (__bf16)((float)ap0[j] + (acc[j] + wa[j] * dsdf) * sig_from_h((float)hv0[j]));
+          as_[2 * t + 1][j] = (__bf16)((float)ap1[j] + (acc[8 + j] + wa[8 + j] * dsdf) * sig_from_h((float)hv1[j]));
         }
         pin2(as_[2 * t], as_[2 * t + 1]);
         pstore<b8>(pblk, live, L::P_ABS + t, lane, as_[2 * t], as_[2 * t + 1], e0b, e1b);
@@ -441,17 +477,17 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PointSrc ps, long npts, co
           pstore<b8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0b, e1b);)
       b8 am[N::HK];
       b8 am0[N::HK];
-      const void* first = gtile<h8, 3>(Wf0, o.v[OFF_W0], 0);   // prefetch the first tile of the next block iteration
+      const Next first = nxt<N, OFF_W0>(sg, Wf0, o);   // prefetch the first tile of the next block iteration
       if constexpr (N::NMID == 2) {
-        layer_s<b8, N::SK, N::HT, N::HK>(sg, Wb, o.v[OFF_WST], gtile<b8, N::HK>(Wb, o.v[OFF_WM1T], 0), as_,
+        layer_s<b8, N::SK, N::HT>(sg, Wb, o.v[OFF_WST], nxt<N, OFF_WM1T>(sg, Wb, o), as_,
                                          AVC_REVERSE(am, L::S_HM + N::HK, L::S_APM + N::HK, L::P_ABM + N::HT));
-        layer_s<b8, N::HK, N::HT, N::HK>(sg, Wb, o.v[OFF_WM1T], gtile<b8, N::HK>(Wb, o.v[OFF_WM0T], 0), am,
+        layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM1T], nxt<N, OFF_WM0T>(sg, Wb, o), am,
                                          AVC_REVERSE(am0, L::S_HM, L::S_APM, L::P_ABM));
-        layer_s<b8, N::HK, N::HT, 3>(sg, Wb, o.v[OFF_WM0T], first, am0, AVC_REVERSE(am, L::S_H1, L::S_AP1, L::P_AB1));
+        layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0T], first, am0, AVC_REVERSE(am, L::S_H1, L::S_AP1, L::P_AB1));
       } else {
-        layer_s<b8, N::SK, N::HT, N::HK>(sg, Wb, o.v[OFF_WST], gtile<b8, N::HK>(Wb, o.v[OFF_WM0T], 0), as_,
+        layer_s<b8, N::SK, N::HT>(sg, Wb, o.v[OFF_WST], nxt<N, OFF_WM0T>(sg, Wb, o), as_,
                                          AVC_REVERSE(am, L::S_HM, L::S_APM, L::P_ABM));
-        layer_s<b8, N::HK, N::HT, 3>(sg, Wb, o.v[OFF_WM0T], first, am, AVC_REVERSE(am0, L::S_H1, L::S_AP1, L::P_AB1));
+        layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0T], first, am, AVC_REVERSE(am0, L::S_H1, L::S_AP1, L::P_AB1));
       }
     }
   }
@@ -472,11 +508,18 @@ extern "C" int avc_render_points_bwd(int net, const float* pts, const float* ray
   int grid = (int)(ngroups < maxg ? ngroups : maxg);
   if (grid < 1) grid = 1;
   hipStream_t s = (hipStream_t)stream;
+  const int lds_bytes = StageT<BWD_G>::LDS_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)mlp_bwd_kernel<NetFull>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipFuncSetAttribute((const void*)mlp_bwd_kernel<NetSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    attr_set = true;
+  }
   if (net == AVC_NET_FULL)
-    hipLaunchKernelGGL((mlp_bwd_kernel<NetFull>), dim3(grid), dim3(256), 0, s, ps, npts, (const h8*)wf16, (const b8*)wbf16,
+    hipLaunchKernelGGL((mlp_bwd_kernel<NetFull>), dim3(grid), dim3(256), lds_bytes, s, ps, npts, (const h8*)wf16, (const b8*)wbf16,
                        tab, o, d_sdf, d_normal, d_rgb, (b8*)panels, (char*)scratch);
   else if (net == AVC_NET_SMALL)
-    hipLaunchKernelGGL((mlp_bwd_kernel<NetSmall>), dim3(grid), dim3(256), 0, s, ps, npts, (const h8*)wf16, (const b8*)wbf16,
+    hipLaunchKernelGGL((mlp_bwd_kernel<NetSmall>), dim3(grid), dim3(256), lds_bytes, s, ps, npts, (const h8*)wf16, (const b8*)wbf16,
                        tab, o, d_sdf, d_normal, d_rgb, (b8*)panels, (char*)scratch);
   else { avc_set_error("unknown net id"); return 1; }
   return avc_check_launch("avc_render_points_bwd");

@@ -3,15 +3,22 @@
 //                         (renderer.py:337-338,187) and of extract_fields (renderer.py:10-25)
 //   avc_render_points_fwd sdf + normal (d sdf/dx) + 6 colour channels per sample point (renderer.py:221-232)
 #include "avc_mlp.h"
+#ifndef FWD_WAVES_PER_EU
+#define FWD_WAVES_PER_EU 2
+#endif
+#ifndef FWD_G
+#define FWD_G 2
+#endif
 #include "../../include/avc.h"
 
 template <class N, int MODE>
-__global__ __launch_bounds__(256, MODE == 0 ? 2 : 1) void mlp_fwd_kernel(PointSrc ps, long npts, const h8* __restrict__ Wf,
+__global__ __launch_bounds__(256, FWD_WAVES_PER_EU) void mlp_fwd_kernel(PointSrc ps, long npts, const h8* __restrict__ Wf,
                                                                        const float* __restrict__ T, AvcOffsets o,
                                                                        float* __restrict__ sdf_out, const int* __restrict__ slot,
                                                                        int ld_out, float* __restrict__ normal_out,
                                                                        float* __restrict__ rgb_out) {
-  __shared__ __attribute__((aligned(16))) char lds[STAGE_LDS_BYTES];
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  typedef StageT<FWD_G> ST;
   const int lane = threadIdx.x & 63;
   const int h = lane >> 5;
   const int p = lane & 31;
@@ -22,8 +29,8 @@ __global__ __launch_bounds__(256, MODE == 0 ? 2 : 1) void mlp_fwd_kernel(PointSr
   long i = blk * 32 + p;
   const bool valid = i < npts;
   if (!valid) i = npts - 1;
-  Stage sg = stage_init(lds);
-  stage_issue<h8, 3>(sg, gtile<h8, 3>(Wf, o.v[OFF_W0], 0), 0);
+  ST sg = stage_init<ST::G>(lds);
+  stage_issue(sg, nxt<N, OFF_W0>(sg, Wf, o), 0);
   float x0[3];
   fetch_point(ps, i, x0);
   long oi = i;
@@ -38,11 +45,11 @@ __global__ __launch_bounds__(256, MODE == 0 ? 2 : 1) void mlp_fwd_kernel(PointSr
   }
   FwdState<N> st;
   st.x[0] = x0[0]; st.x[1] = x0[1]; st.x[2] = x0[2];
-  sdf_trunk<N, N::SK + 3>(sg, Wf, T, o, h, st, gtile<h8, N::SK + 3>(Wf, o.v[OFF_WL], 0));
+  sdf_trunk<N>(sg, Wf, T, o, h, st, nxt<N, OFF_WL>(sg, Wf, o));
   h8 feat[N::HK];
-  sdf_feature<N, N::SK>(sg, Wf, T, o, h, st, feat, gtile<h8, N::SK>(Wf, o.v[OFF_WST], 0));
+  sdf_feature<N>(sg, Wf, T, o, h, st, feat, nxt<N, OFF_WST>(sg, Wf, o));
   float n[3];
-  sdf_normal<N, N::HK + 1>(sg, Wf, T, o, h, st, n, gtile<h8, N::HK + 1>(Wf, o.v[OFF_C0], 0));
+  sdf_normal<N>(sg, Wf, T, o, h, st, n, nxt<N, OFF_C0>(sg, Wf, o));
   float rgb[4];
   color_forward<N>(sg, Wf, T, o, h, st.x, n, feat, rgb);
   if (valid) {
@@ -73,11 +80,18 @@ static int launch_fwd(int net, PointSrc ps, long npts, const void* wf, const flo
   hipStream_t s = (hipStream_t)stream;
   const int wpb = 4;   // wavefronts per workgroup
   const int grid = grid_for(npts, wpb, 0x7fffffff);
+  const int lds_bytes = StageT<FWD_G>::LDS_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)mlp_fwd_kernel<NetFull, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipFuncSetAttribute((const void*)mlp_fwd_kernel<NetSmall, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    attr_set = true;
+  }
   if (net == AVC_NET_FULL)
-    hipLaunchKernelGGL((mlp_fwd_kernel<NetFull, MODE>), dim3(grid), dim3(64 * wpb), 0, s, ps, npts, (const h8*)wf, tab, o,
+    hipLaunchKernelGGL((mlp_fwd_kernel<NetFull, MODE>), dim3(grid), dim3(64 * wpb), lds_bytes, s, ps, npts, (const h8*)wf, tab, o,
                        sdf_out, slot, ld_out, normal_out, rgb_out);
   else if (net == AVC_NET_SMALL)
-    hipLaunchKernelGGL((mlp_fwd_kernel<NetSmall, MODE>), dim3(grid), dim3(64 * wpb), 0, s, ps, npts, (const h8*)wf, tab, o,
+    hipLaunchKernelGGL((mlp_fwd_kernel<NetSmall, MODE>), dim3(grid), dim3(64 * wpb), lds_bytes, s, ps, npts, (const h8*)wf, tab, o,
                        sdf_out, slot, ld_out, normal_out, rgb_out);
   else {
     avc_set_error("unknown net id");

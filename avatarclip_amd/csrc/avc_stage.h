@@ -2,26 +2,41 @@
 //
 // Every wavefront of a workgroup walks the same static sequence of 32-row weight tiles.  Instead of each wave
 // streaming its own copy of every 1-KiB fragment from L2 (what caps the un-staged kernels at ~17 % of MFMA peak),
-// the workgroup copies each tile ONCE into LDS with direct global->LDS DMA (global_load_lds_dwordx4; the packed
+// the workgroup copies the tiles ONCE into LDS with direct global->LDS DMA (global_load_lds_dwordx4; the packed
 // fragment order is exactly the lane-linear image that instruction writes) and every wave reads its A operands
-// with conflict-free ds_read_b128.  Two LDS buffers: tile t+1 is in flight while tile t feeds the MFMAs; one
-// __syncthreads per tile orders both the RAW (DMA landed) and the WAR (buffer free) hazard.
+// with conflict-free ds_read_b128.
+//
+// Granularity: a GROUP of up to G consecutive tiles of one layer (G = 4: half a 256-wide layer, 64-68 KiB).  Two LDS
+// buffers: group g+1 is in flight while group g feeds the MFMAs; ONE __syncthreads per group orders both the RAW
+// (DMA landed) and the WAR (buffer free) hazard.  Coarse groups matter: hipcc drains vmcnt(0) before a barrier while
+// an LDS-DMA is pending, which also waits for every panel/scratch store of the epilogues -- per-tile barriers cost an
+// L2 round trip per tile (measured: SQ_WAIT_ANY 78 % of wave cycles in the backward kernel), per-group barriers a
+// quarter of that, and a 64 KiB copy has half a layer of MFMA work to hide under.
 #pragma once
 #include "avc_common.h"
 
-#define STAGE_BUF_BYTES (18 * 1024)   // >= 17 k-steps x 1 KiB (largest tile: K = skip features + PE slots / H + [x,n])
-#define STAGE_LDS_BYTES (2 * STAGE_BUF_BYTES)
+#define STAGE_TILE_BYTES (17 * 1024)   // largest tile: 17 k-steps x 1 KiB (K = skip features + PE slots / H + [x,n])
 
-struct Stage {
-  char* lds;   // STAGE_LDS_BYTES, 16-byte aligned
-  int par;     // buffer holding the tile that is consumed next
+struct Next {          // the group that follows in the static tile sequence
+  const void* ptr;     // nullptr = nothing follows
+  int chunks;          // 1-KiB chunks to copy
+};
+
+template <int G_>
+struct StageT {
+  static constexpr int G = G_;
+  static constexpr int BUF_BYTES = G_ * STAGE_TILE_BYTES;
+  static constexpr int LDS_BYTES = 2 * G_ * STAGE_TILE_BYTES;
+  char* lds;   // LDS_BYTES, 16-byte aligned
+  int par;     // buffer holding the group that is consumed next
   int wave;    // wave index in the workgroup (SGPR)
   int lane;
   int nw;      // waves per workgroup
 };
 
-__device__ __forceinline__ Stage stage_init(char* lds) {
-  Stage st;
+template <int G>
+__device__ __forceinline__ StageT<G> stage_init(char* lds) {
+  StageT<G> st;
   st.lds = lds;
   st.par = 0;
   st.wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -30,38 +45,31 @@ __device__ __forceinline__ Stage stage_init(char* lds) {
   return st;
 }
 
-template <typename V, int KS>
-__device__ __forceinline__ void stage_issue(const Stage& st, const void* __restrict__ gtile_, int buf) {
-  // gtile: first 16-B chunk of the tile (lane 0, k-step 0); chunk c of the tile is 64 lanes x 16 B = 1 KiB
-  // (V only documents the element type: f16 and bf16 tiles have the same byte image)
-  const char* gtile = reinterpret_cast<const char*>(gtile_);
-  char* dst = st.lds + buf * STAGE_BUF_BYTES;
-  for (int c = st.wave; c < KS; c += st.nw) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gtile + c * 1024 + st.lane * 16),
+template <class ST>
+__device__ __forceinline__ void stage_issue(const ST& st, const Next& nx, int buf) {
+  if (!nx.ptr) return;
+  const char* g = reinterpret_cast<const char*>(nx.ptr);
+  char* dst = st.lds + buf * ST::BUF_BYTES;
+  for (int c = st.wave; c < nx.chunks; c += st.nw) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + c * 1024 + st.lane * 16),
                                      (__attribute__((address_space(3))) void*)(dst + c * 1024), 16, 0, 0);
   }
 }
 
-// Consume the staged tile (KS k-steps) against the register-resident B operands `in`, after issuing the copy of the
-// next tile (KSN k-steps at gnext; nullptr = nothing follows).
-template <typename V, int KS, int KSN>
-__device__ __forceinline__ facc tile_gemm_s(Stage& st, const void* __restrict__ gnext, const V (&in)[KS]) {
-  __syncthreads();   // tile in buffer `par` has landed (hipcc drains vmcnt before the barrier); buffer par^1 is free
-  if (gnext) stage_issue<V, KSN>(st, gnext, st.par ^ 1);
-  const V* a = reinterpret_cast<const V*>(st.lds + st.par * STAGE_BUF_BYTES) + st.lane;
+// MFMAs of tile j of the current group (KS k-steps per tile) against the register-resident B operands
+template <typename V, int KS, class ST>
+__device__ __forceinline__ facc tile_mma(const ST& st, int j, const V (&in)[KS]) {
+  const V* a = reinterpret_cast<const V*>(st.lds + st.par * ST::BUF_BYTES + j * KS * 1024) + st.lane;
   facc acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
   for (int s = 0; s < KS; ++s) acc = MF<V>::mma(a[s * 64], in[s], acc);
-  st.par ^= 1;
   return acc;
 }
-template <typename V, int KA, int KB, int KSN>
-__device__ __forceinline__ facc tile_gemm2_s(Stage& st, const void* __restrict__ gnext, const V (&ina)[KA], const V (&inb)[KB]) {
-  __syncthreads();
-  if (gnext) stage_issue<V, KSN>(st, gnext, st.par ^ 1);
-  const V* a = reinterpret_cast<const V*>(st.lds + st.par * STAGE_BUF_BYTES) + st.lane;
+template <typename V, int KA, int KB, class ST>
+__device__ __forceinline__ facc tile_mma2(const ST& st, int j, const V (&ina)[KA], const V (&inb)[KB]) {
+  const V* a = reinterpret_cast<const V*>(st.lds + st.par * ST::BUF_BYTES + j * (KA + KB) * 1024) + st.lane;
   facc acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -69,12 +77,5 @@ __device__ __forceinline__ facc tile_gemm2_s(Stage& st, const void* __restrict__
   for (int s = 0; s < KA; ++s) acc = MF<V>::mma(a[s * 64], ina[s], acc);
 #pragma unroll
   for (int s = 0; s < KB; ++s) acc = MF<V>::mma(a[(KA + s) * 64], inb[s], acc);
-  st.par ^= 1;
   return acc;
-}
-
-// global address of tile t of a packed weight (KS k-steps per tile), lane-0 chunk
-template <typename V, int KS>
-__device__ __forceinline__ const V* gtile(const V* blob, int off, int t) {
-  return blob + (off >> 3) + (long)(t * KS) * 64;
 }

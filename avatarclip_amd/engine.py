@@ -73,7 +73,7 @@ class Engine:
     PROFILE = False               # bench.py: record (name, points, start_event, end_event) per kernel launch group
     prof_events = []
     WG_NSPLIT = 512               # split-K workgroups per weight-gradient pair (2 per CU)
-    MAX_BWD_WAVES = 1024          # 256 CUs x 4 wavefronts (one per SIMD: the backward kernel uses the full RF)
+    MAX_BWD_WAVES = 2048          # 256 CUs x 4 wavefronts (one per SIMD: the backward kernel uses the full RF)
     PANEL_BYTES_BUDGET = 12 << 30  # weight-gradient operand panels per chunk of points
 
     def __init__(self, spec: PK.NetSpec, device):

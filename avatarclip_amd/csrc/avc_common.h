@@ -22,6 +22,12 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 #define AVC_BETA 100.0f
 #define AVC_INV_BETA 0.01f
+// Base-2 softplus units.  With S = beta*log2(e) the kernels carry  t = S*a  (pre-activation) and  H = S*h  (activation):
+//   H = log2(1 + 2^t) = max(t,0) + log2(1 + 2^-|t|),   sigma(beta a) = 1 - 2^-H,
+// i.e. one v_exp_f32 + one v_log_f32 and 3 plain VALU ops per element, no range fix-ups (arguments are in the safe
+// range by construction).  S is folded into the packed layer-0 weights and the biases, 1/S into the last layer
+// (packing.py); hidden HxH weights are unchanged because W (S h) = S (W h).
+#define AVC_S 144.26950408889634f
 
 // ---- offsets of the packed parameter blobs (element units of the blob's dtype); mirrored by packing.py,
 // ---- which parses this enum.  *_T = transposed weight (rows = in-features).
@@ -31,6 +37,7 @@ enum AvcOff {
   OFF_W0T, OFF_WM0T, OFF_WM1T, OFF_WST, OFF_WLT,         // SDF transposed (WLT: rows = [skip feats | pe slots], K = H feature rows 1..H)
   OFF_C0, OFF_CM0, OFF_CH,                               // colour forward: layer0 (K = feat + [x,n]), middle, heads(6 rows)
   OFF_C0T, OFF_CM0T, OFF_CHT,                            // colour transposed
+  OFF_W0G,                                               // layer 0, forward orientation, UNscaled (second-order sweep)
   // fp32 tables
   OFF_B0, OFF_BM0, OFF_BM1, OFF_BS, OFF_BL, OFF_BL0,     // packed biases (acc order), BL0 = scalar sdf bias
   OFF_WL0_ACC, OFF_WL0_FRAG, OFF_WL0_PE,                 // row 0 of the last layer / sqrt2 in acc order, frag order, pe-slot order
@@ -97,13 +104,13 @@ __device__ __forceinline__ void load8(const float* __restrict__ tab, int s, int 
   out[4] = b[0]; out[5] = b[1]; out[6] = b[2]; out[7] = b[3];
 }
 
-__device__ __forceinline__ float softplus100(float a) {
-  // nn.Softplus(beta=100): log(1+exp(100 a))/100 (fields.py:68); stable form
-  float e = __expf(-fabsf(a) * AVC_BETA);
-  return fmaxf(a, 0.f) + __logf(1.f + e) * AVC_INV_BETA;
+__device__ __forceinline__ float softplus2(float t) {
+  // H = S * Softplus_beta100(t / S)  (nn.Softplus(beta=100), fields.py:68) in base-2 units; raw v_exp_f32 / v_log_f32
+  const float e = __builtin_amdgcn_exp2f(-fabsf(t));
+  return fmaxf(t, 0.f) + __builtin_amdgcn_logf(1.f + e);
 }
-// sigma(beta a) recovered from h = softplus(a):  1 - exp(-beta h)
-__device__ __forceinline__ float sig_from_h(float h) { return 1.f - __expf(-AVC_BETA * h); }
+// sigma(beta a) recovered from H = S * softplus(a):  1 - 2^-H
+__device__ __forceinline__ float sig_from_h(float H) { return 1.f - __builtin_amdgcn_exp2f(-H); }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
 template <typename V> __device__ __forceinline__ void set8(V& f, int j, float v) { f[j] = (typename MF<V>::S)v; }

@@ -60,6 +60,7 @@ AVC_TI(OFF_W0, 3, N::HT)          AVC_TI(OFF_WM0, N::HK, N::HT)   AVC_TI(OFF_WM1
 AVC_TI(OFF_WL, N::SK + 3, N::HT)  AVC_TI(OFF_W0T, N::HK, 2)       AVC_TI(OFF_WM0T, N::HK, N::HT) AVC_TI(OFF_WM1T, N::HK, N::HT)
 AVC_TI(OFF_WST, N::SK, N::HT)     AVC_TI(OFF_WLT, N::HK, N::ST)   AVC_TI(OFF_C0, N::HK + 1, N::HT) AVC_TI(OFF_CM0, N::HK, N::HT)
 AVC_TI(OFF_CH, N::HK, 1)          AVC_TI(OFF_C0T, N::HK, N::HT + 1) AVC_TI(OFF_CM0T, N::HK, N::HT) AVC_TI(OFF_CHT, 1, N::HT)
+AVC_TI(OFF_W0G, 3, N::HT)
 
 // descriptor of the FIRST group of packed weight OFF (what the layer before it prefetches)
 template <class N, int OFF, class ST>
@@ -165,27 +166,27 @@ __device__ __forceinline__ void sdf_trunk(ST& sg, const h8* __restrict__ Wf, con
   layer_s<h8, 3, N::HT>(sg, Wf, o.v[OFF_W0], nxt<N, OFF_WM0>(sg, Wf, o), st.pef, AVC_EPI(
     float b[16], a[16];
     load16(T + o.v[OFF_B0], t, h, b);
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);
     acc_to_frags(a, st.h1[2 * t], st.h1[2 * t + 1]);
   ));
   if constexpr (N::NMID == 2) {
     layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wf, o), st.h1, AVC_EPI(
       float b[16], a[16];
       load16(T + o.v[OFF_BM0], t, h, b);
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);
       acc_to_frags(a, st.hm[0][2 * t], st.hm[0][2 * t + 1]);
     ));
     layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wf, o), st.hm[0], AVC_EPI(
       float b[16], a[16];
       load16(T + o.v[OFF_BM1], t, h, b);
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);
       acc_to_frags(a, st.hm[1][2 * t], st.hm[1][2 * t + 1]);
     ));
   } else {
     layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wf, o), st.h1, AVC_EPI(
       float b[16], a[16];
       load16(T + o.v[OFF_BM0], t, h, b);
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);
       acc_to_frags(a, st.hm[0][2 * t], st.hm[0][2 * t + 1]);
     ));
   }
@@ -193,7 +194,7 @@ __device__ __forceinline__ void sdf_trunk(ST& sg, const h8* __restrict__ Wf, con
   layer_s<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], gnext, st.hm[N::NMID - 1], AVC_EPI(
     float b[16], a[16];
     load16(T + o.v[OFF_BS], t, h, b);
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);
     load16(T + o.v[OFF_WL0_ACC], t, h, b);
     _Pragma("unroll") for (int r = 0; r < 16; ++r) part += b[r] * a[r];
     acc_to_frags(a, st.hs[2 * t], st.hs[2 * t + 1]);
@@ -228,7 +229,7 @@ __device__ __forceinline__ float sdf_only(ST& sg, const h8* __restrict__ Wf, con
       layer_s<h8, 3, N::HT>(sg, Wf, o.v[OFF_W0], nxt<N, OFF_WM0>(sg, Wf, o), pef, AVC_EPI(
         float b[16], a[16];
         load16(T + o.v[OFF_B0], t, h, b);
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);
         acc_to_frags(a, h1[2 * t], h1[2 * t + 1]);
       ));
     }
@@ -237,20 +238,20 @@ __device__ __forceinline__ float sdf_only(ST& sg, const h8* __restrict__ Wf, con
       layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wf, o), h1, AVC_EPI(
         float b[16], a[16];
         load16(T + o.v[OFF_BM0], t, h, b);
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);
         acc_to_frags(a, hm0[2 * t], hm0[2 * t + 1]);
       ));
       layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wf, o), hm0, AVC_EPI(
         float b[16], a[16];
         load16(T + o.v[OFF_BM1], t, h, b);
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);
         acc_to_frags(a, hlast[2 * t], hlast[2 * t + 1]);
       ));
     } else {
       layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wf, o), h1, AVC_EPI(
         float b[16], a[16];
         load16(T + o.v[OFF_BM0], t, h, b);
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);
         acc_to_frags(a, hlast[2 * t], hlast[2 * t + 1]);
       ));
     }
@@ -259,7 +260,7 @@ __device__ __forceinline__ float sdf_only(ST& sg, const h8* __restrict__ Wf, con
     float b[16], w[16];
     load16(T + o.v[OFF_BS], t, h, b);
     load16(T + o.v[OFF_WL0_ACC], t, h, w);
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) part += w[r] * softplus100(acc[r] + b[r]);
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) part += w[r] * softplus2(acc[r] + b[r]);
   ));
   return xhalf_sum(part) + T[o.v[OFF_BL0]];
 }

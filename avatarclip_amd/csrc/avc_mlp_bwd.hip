@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256, BWD_WAVES_PER_EU) void mlp_bwd_kernel(PointSrc
       h8 hs[N::SK];
 #define AVC_FWD_KEEP(OFFB, OUT, SCR, PT)                                                     \
   AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
-          _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus100(acc[r] + b[r]);  \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);  \
           acc_to_frags(a, OUT[2 * t], OUT[2 * t + 1]);                                        \
           scr_store(scr, (SCR) + 2 * t, lane, OUT[2 * t]); scr_store(scr, (SCR) + 2 * t + 1, lane, OUT[2 * t + 1]); \
           pstore<h8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0h, e1h);)
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256, BWD_WAVES_PER_EU) void mlp_bwd_kernel(PointSrc
       }
       // d r0 = C0^T delta1: HT feature tiles, then the [x,n] tile (rows 3,4,5 = d n)
       float dn_acc[3] = {0.f, 0.f, 0.f};
-      layer_s<b8, N::HK, N::HT + 1>(sg, Wb, o.v[OFF_C0T], nxt<N, OFF_W0>(sg, Wb, o), d1, AVC_EPI(
+      layer_s<b8, N::HK, N::HT + 1>(sg, Wb, o.v[OFF_C0T], nxt<N, OFF_W0G>(sg, Wb, o), d1, AVC_EPI(
         if (t < N::HT) {
           _Pragma("unroll") for (int j = 0; j < 8; ++j) {
             dfeat[2 * (t < N::HT ? t : 0)][j] = (__bf16)acc[j];
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256, BWD_WAVES_PER_EU) void mlp_bwd_kernel(PointSrc
         nbar[2] = d_normal[3 * i + 2] * vmask + (h ? a1 : o1);
       }
     }
-    const float dsdf = d_sdf[i] * vmask;
+    const float dsdfS = d_sdf[i] * vmask * AVC_S;   // OFF_WL0_ACC holds W_last[0,:]/(S sqrt2): undo S for the gradient use
     if (live) {   // A-panels with a single live feature: d_sdf and the constant 1 (row 0 of the last layer)
       const int nf = lane & 31;
       b8 k0 = zero_frag<b8>(), k1 = zero_frag<b8>(), o0 = zero_frag<b8>(), o1 = zero_frag<b8>();
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256, BWD_WAVES_PER_EU) void mlp_bwd_kernel(PointSrc
           scr_store(scrb, (SAP) + 2 * t, lane, a0); scr_store(scrb, (SAP) + 2 * t + 1, lane, a1);           \
           pstore<b8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0b, e1b);)
       b8 gb1[N::HK];
-      layer_s<b8, 3, N::HT>(sg, Wb, o.v[OFF_W0], nxt<N, OFF_WM0>(sg, Wb, o), gb0,
+      layer_s<b8, 3, N::HT>(sg, Wb, o.v[OFF_W0G], nxt<N, OFF_WM0>(sg, Wb, o), gb0,
                                    AVC_SECOND(gb1, L::S_H1, L::S_Q1, L::S_AP1, L::P_GBH1, false));
       b8 gbm[N::HK];
       b8 gbs[N::SK];
@@ -460,8 +460,8 @@ __global__ __launch_bounds__(256, BWD_WAVES_PER_EU) void mlp_bwd_kernel(PointSrc
         const h8 hv0 = scr_load(scr, L::S_HS + 2 * t, lane), hv1 = scr_load(scr, L::S_HS + 2 * t + 1, lane);
         const b8 ap0 = scr_load(scrb, L::S_APS + 2 * t, lane), ap1 = scr_load(scrb, L::S_APS + 2 * t + 1, lane);
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {
-          as_[2 * t][j] = (__bf16)((float)ap0[j] + (acc[j] + wa[j] * dsdf) * sig_from_h((float)hv0[j]));
-          as_[2 * t + 1][j] = (__bf16)((float)ap1[j] + (acc[8 + j] + wa[8 + j] * dsdf) * sig_from_h((float)hv1[j]));
+          as_[2 * t][j] = (__bf16)((float)ap0[j] + (acc[j] + wa[j] * dsdfS) * sig_from_h((float)hv0[j]));
+          as_[2 * t + 1][j] = (__bf16)((float)ap1[j] + (acc[8 + j] + wa[8 + j] * dsdfS) * sig_from_h((float)hv1[j]));
         }
         pin2(as_[2 * t], as_[2 * t + 1]);
         pstore<b8>(pblk, live, L::P_ABS + t, lane, as_[2 * t], as_[2 * t + 1], e0b, e1b);

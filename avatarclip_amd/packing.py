@@ -20,6 +20,7 @@ from typing import Dict, List, Tuple
 import numpy as np
 
 SQ2 = math.sqrt(2.0)
+S_B2 = 100.0 * math.log2(math.e)   # base-2 softplus unit (AVC_S in csrc/avc_common.h)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
@@ -207,9 +208,13 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
     idx16, sc16, offsets = [], [], np.zeros(OFF_COUNT, np.int32)
     cur16 = [0]
 
-    def pack(off_name, wname, rows, kmap, transposed=False, scale=1.0):
+    def pack(off_name, wname, rows, kmap, transposed=False, scale=1.0, kscale=None):
         NT, KS = len(rows) // 32, kmap.shape[0]
         arr = np.full((NT, KS, 64, 8), ZERO, np.int64)
+        sca = np.full((NT, KS, 64, 8), scale, np.float32)
+        if kscale is not None:   # per k-slot scale [KS, 2, 8]
+            for lane in range(64):
+                sca[:, :, lane, :] *= kscale[None, :, lane >> 5, :]
         for lane in range(64):
             hh, i = lane >> 5, lane & 31
             for t in range(NT):
@@ -226,16 +231,18 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
                 arr[t, :, lane, :] = np.where(ok, flat, ZERO)
         offsets[OFF[off_name]] = cur16[0]
         idx16.append(arr.reshape(-1))
-        sc16.append(np.full(arr.size, scale, np.float32))
+        sc16.append(sca.reshape(-1))
         cur16[0] += arr.size
 
-    pack("OFF_W0", "sdf.W0", rows_std(H, HT), kmap_pe(True))
+    pack("OFF_W0", "sdf.W0", rows_std(H, HT), kmap_pe(True), scale=S_B2)          # forward: t1 = S a1
+    pack("OFF_W0G", "sdf.W0", rows_std(H, HT), kmap_pe(True))                     # second-order sweep: unscaled
     pack("OFF_WM0", "sdf.W1", rows_std(H, HT), kmap_std(H, HK))
     if NMID == 2:
         pack("OFF_WM1", "sdf.W2", rows_std(H, HT), kmap_std(H, HK))
     pack("OFF_WS", ls, rows_std(SKIP, ST), kmap_std(H, HK))
+    ks_last = np.concatenate([np.full((SK, 2, 8), 1.0 / S_B2, np.float32), np.ones((3, 2, 8), np.float32)], 0)
     pack("OFF_WL", ll, rows_std(H, HT, shift=1), np.concatenate([kmap_std(SKIP, SK), kmap_pe(True, shift=SKIP)], 0),
-         scale=1.0 / SQ2)
+         scale=1.0 / SQ2, kscale=ks_last)                                         # skip features arrive as H = S h
     pack("OFF_W0T", "sdf.W0", rows_pe(), kmap_std(H, HK), transposed=True)
     pack("OFF_WM0T", "sdf.W1", rows_std(H, HT), kmap_std(H, HK), transposed=True)
     if NMID == 2:
@@ -276,11 +283,11 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
                         arr[t, h, r] = pbase[bname] + f + shift
         return arr
 
-    table("OFF_B0", bias_tab("sdf.b0", H, HT))
-    table("OFF_BM0", bias_tab("sdf.b1", H, HT))
+    table("OFF_B0", bias_tab("sdf.b0", H, HT), S_B2)
+    table("OFF_BM0", bias_tab("sdf.b1", H, HT), S_B2)
     if NMID == 2:
-        table("OFF_BM1", bias_tab("sdf.b2", H, HT))
-    table("OFF_BS", bias_tab(bs, SKIP, ST))
+        table("OFF_BM1", bias_tab("sdf.b2", H, HT), S_B2)
+    table("OFF_BS", bias_tab(bs, SKIP, ST), S_B2)
     table("OFF_BL", bias_tab(bl, H, HT, shift=1))
     table("OFF_BL0", [pbase[bl]])
     a = np.full((ST, 2, 16), ZERO, np.int64)
@@ -290,7 +297,7 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
                 f = 32 * t + acc_row(r, h)
                 if f < SKIP:
                     a[t, h, r] = pbase[ll] + f   # row 0 of the last layer
-    table("OFF_WL0_ACC", a, 1.0 / SQ2)
+    table("OFF_WL0_ACC", a, 1.0 / (SQ2 * S_B2))   # multiplies H = S h in the fp32 sdf dot product
     a = np.full((SK, 2, 8), ZERO, np.int64)
     for s in range(SK):
         for h in range(2):
@@ -384,17 +391,17 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
         wn, bn = "sdf.W%d" % (m + 1), "sdf.b%d" % (m + 1)
         pin = P["H1"] if m == 0 else P["HM"] + (m - 1) * HT
         gin = P["GBH1"] if m == 0 else P["GBHM"] + (m - 1) * HT
-        add_pair(P["ABM"] + m * HT, HT, pin, HT, wn, feat_std(H), feat_std(H), bname=bn)
+        add_pair(P["ABM"] + m * HT, HT, pin, HT, wn, feat_std(H), feat_std(H), scale=1 / S_B2, bname=bn)
         add_pair(P["GAM"] + m * HT, HT, gin, HT, wn, feat_std(H), feat_std(H))
     # skip layer
-    add_pair(P["ABS"], ST, P["HM"] + (NMID - 1) * HT, HT, ls, feat_std(SKIP), feat_std(H), bname=bs)
+    add_pair(P["ABS"], ST, P["HM"] + (NMID - 1) * HT, HT, ls, feat_std(SKIP), feat_std(H), scale=1 / S_B2, bname=bs)
     add_pair(P["GAS"], ST, P["GBHM"] + (NMID - 1) * HT, HT, ls, feat_std(SKIP), feat_std(H))
     # last layer: rows 1..H (ybar[1:]) and row 0 (d_sdf ; second-order term through the constant-one panel)
     r1 = lambda f: (f + 1) if f < H else -1
     r0 = lambda f: 0 if f == 0 else -1
-    add_pair(P["DFEAT"], HT, P["HS"], ST, ll, r1, feat_std(SKIP), scale=1 / SQ2, bname=bl)
+    add_pair(P["DFEAT"], HT, P["HS"], ST, ll, r1, feat_std(SKIP), scale=1 / (SQ2 * S_B2), bname=bl)
     add_pair(P["DFEAT"], HT, P["H0"], 2, ll, r1, feat_pe(True, shift=SKIP), scale=1 / SQ2)
-    add_pair(P["SDF"], 1, P["HS"], ST, ll, r0, feat_std(SKIP), scale=1 / SQ2, bname=bl)
+    add_pair(P["SDF"], 1, P["HS"], ST, ll, r0, feat_std(SKIP), scale=1 / (SQ2 * S_B2), bname=bl)
     add_pair(P["SDF"], 1, P["H0"], 2, ll, r0, feat_pe(True, shift=SKIP), scale=1 / SQ2)
     add_pair(P["ONE"], 1, P["GBHS"], ST, ll, r0, feat_std(SKIP), scale=1 / SQ2)
     add_pair(P["ONE"], 1, P["GB0"], 2, ll, r0, feat_pe(False, shift=SKIP), scale=1 / SQ2)

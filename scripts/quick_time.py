@@ -16,8 +16,18 @@ def main(res=224, small=False):
         col = fields.RenderingNetwork(d_feature=256, mode="no_view_dir", d_in=6, d_out=3, d_hidden=256, n_layers=2, extra_color=True)
     var = fields.SingleVarianceNetwork(0.3)
     sdf, col, var = sdf.to(dev), col.to(dev), var.to(dev)
+    if os.environ.get("QT_NOISE"):
+        with torch.no_grad():
+            for p_ in list(sdf.parameters()) + list(col.parameters()):
+                p_.add_(torch.randn_like(p_) * float(os.environ["QT_NOISE"]))
     ren = renderer.NeuSRenderer(None, sdf, var, col, 32, 32, 0, 4, 1.0, True)
-    pose = torch.from_numpy(O.lookat(np.array([0., 0.2, 1.5]), np.zeros(3), np.array([0., 1, 0]))).float()
+    eye = np.array([0., 0.2, 1.5]); at = np.zeros(3)
+    if os.environ.get("QT_RANDCAM"):
+        from avatarclip_amd import utils as U
+        np.random.seed(int(os.environ["QT_RANDCAM"]))
+        e, th, ph, fr = U.random_eye_normal(); at = U.random_at(); eye = e + at
+        print("random camera eye", eye, "at", at)
+    pose = torch.from_numpy(O.lookat(eye, at, np.array([0., 1, 0]))).float()
     o, v = O.gen_rays_pose(pose, res, res, 0.5 * res / np.tan(np.pi / 6))
     ro, rd = o.reshape(-1, 3).contiguous().to(dev), v.reshape(-1, 3).contiguous().to(dev)
     near, far = O.near_far_from_sphere(ro, rd)
@@ -36,7 +46,18 @@ def main(res=224, small=False):
         t[4].record()
         torch.cuda.synchronize()
         return [t[i].elapsed_time(t[i + 1]) for i in range(4)], loss.item()
-    for i in range(4):
+    clip = None
+    if os.environ.get("QT_CLIP"):
+        from avatarclip_amd import clip_vit
+        from avatarclip_amd.runner import clip_vit_random_state_dict
+        clip = clip_vit.ClipVisionB32(clip_vit_random_state_dict(0), dev)
+    for i in range(int(os.environ.get("QT_ITERS", "4"))):
+        if clip is not None:
+            for _ in range(2):
+                img = torch.rand(1, 3, 224, 224, device=dev, requires_grad=True)
+                clip.encode_image(img).sum().backward()
+        if os.environ.get("QT_SLEEP"):
+            torch.cuda.synchronize(); time.sleep(float(os.environ["QT_SLEEP"]))
         ms, l = step()
         print("res %d small %s iter %d: pack %.2f ms, sample %.2f ms, fwd %.2f ms, bwd %.2f ms, loss %.4f" % (res, small, i, *ms, l), flush=True)
     R = res * res

@@ -65,12 +65,13 @@ def tile_gemm(blob, off_name, KS, t, frags):
     return acc
 
 
-def softplus(a):
-    return np.maximum(a, 0) + np.log1p(np.exp(-np.abs(a) * BETA)) / BETA
+def softplus(t):
+    """softplus2 of avc_common.h: base-2 units, t = S a, returns H = S h."""
+    return np.maximum(t, 0) + np.log2(1.0 + np.exp2(-np.abs(t)))
 
 
-def sig_from_h(h):
-    return 1.0 - np.exp(-BETA * h)
+def sig_from_h(H):
+    return 1.0 - np.exp2(-H)
 
 
 def pe_compute(x):
@@ -328,7 +329,7 @@ def backward_wave(spec: PK.NetSpec, blob: Blob, x, d_sdf, d_n, d_rgb):
             ap += [acc[:, :8] * qfr[2 * t], acc[:, 8:] * qfr[2 * t + 1]]
         store_act(ptile, gout, NT)
         return gout, ap
-    gb1, ap1 = second("OFF_W0", 3, HT, gb0, st["h1"], q_1, P["GBH1"])
+    gb1, ap1 = second("OFF_W0G", 3, HT, gb0, st["h1"], q_1, P["GBH1"])
     gbm, apm = [], []
     g_in = gb1
     for m in range(NM):
@@ -342,8 +343,8 @@ def backward_wave(spec: PK.NetSpec, blob: Blob, x, d_sdf, d_n, d_rgb):
     for t in range(ST):
         acc = tile_gemm(blob, "OFF_WLT", HK, t, dfeat)
         wa = blob.load16("OFF_WL0_ACC", t)
-        as_ += [aps[2 * t] + (acc[:, :8] + wa[:, :8] * dsdf[:, None]) * sig_from_h(st["hs"][2 * t]),
-                aps[2 * t + 1] + (acc[:, 8:] + wa[:, 8:] * dsdf[:, None]) * sig_from_h(st["hs"][2 * t + 1])]
+        as_ += [aps[2 * t] + (acc[:, :8] + wa[:, :8] * dsdf[:, None] * PK.S_B2) * sig_from_h(st["hs"][2 * t]),
+                aps[2 * t + 1] + (acc[:, 8:] + wa[:, 8:] * dsdf[:, None] * PK.S_B2) * sig_from_h(st["hs"][2 * t + 1])]
     store_act(P["ABS"], as_, ST)
 
     def reverse(offw, KS, NT, ain, hfr, apfr, ptile):

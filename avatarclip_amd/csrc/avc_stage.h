@@ -56,6 +56,27 @@ __device__ __forceinline__ void stage_issue(const ST& st, const Next& nx, int bu
   }
 }
 
+
+// hipcc sinks every ds_read_b128 next to the MFMA that consumes it (ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma, one LDS
+// round trip per MFMA, seen in the ISA of every kernel built on this engine).  pinN() makes a batch of fragments opaque at a
+// program point, so the reads of the whole batch are issued back to back and the MFMA chain then runs at the matrix pipe's
+// own rate; the second half's reads are already in flight while the first half's MFMAs execute.
+template <typename V>
+__device__ __forceinline__ void pin4(V& a, V& b, V& c, V& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+template <typename V, int KS>
+__device__ __forceinline__ facc mma_chain_lds(const V* __restrict__ a_lds /* lane's chunk of k-step 0 */, const V (&in)[KS], facc acc) {
+  V a[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) a[s] = a_lds[s * 64];
+#pragma unroll
+  for (int s = 0; s < KS; s += 4) {
+    if (s + 3 < KS) pin4(a[s], a[s + 1], a[s + 2], a[s + 3]);
+#pragma unroll
+    for (int k = s; k < s + 4 && k < KS; ++k) acc = MF<V>::mma(a[k], in[k], acc);
+  }
+  return acc;
+}
+
 // MFMAs of tile j of the current group (KS k-steps per tile) against the register-resident B operands
 template <typename V, int KS, class ST>
 __device__ __forceinline__ facc tile_mma(const ST& st, int j, const V (&in)[KS]) {
@@ -63,9 +84,7 @@ __device__ __forceinline__ facc tile_mma(const ST& st, int j, const V (&in)[KS])
   facc acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-  for (int s = 0; s < KS; ++s) acc = MF<V>::mma(a[s * 64], in[s], acc);
-  return acc;
+  return mma_chain_lds<V, KS>(a, in, acc);
 }
 template <typename V, int KA, int KB, class ST>
 __device__ __forceinline__ facc tile_mma2(const ST& st, int j, const V (&ina)[KA], const V (&inb)[KB]) {
@@ -73,9 +92,6 @@ __device__ __forceinline__ facc tile_mma2(const ST& st, int j, const V (&ina)[KA
   facc acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-  for (int s = 0; s < KA; ++s) acc = MF<V>::mma(a[s * 64], ina[s], acc);
-#pragma unroll
-  for (int s = 0; s < KB; ++s) acc = MF<V>::mma(a[(KA + s) * 64], inb[s], acc);
-  return acc;
+  acc = mma_chain_lds<V, KA>(a, ina, acc);
+  return mma_chain_lds<V, KB>(a + KA * 64, inb, acc);
 }

@@ -129,9 +129,13 @@ class Engine:
     def pack(self, flatP: torch.Tensor) -> Packed:
         return Packed(self.dl, flatP)
 
-    def _bufs(self, nblk_chunk):
+    def _scratch_buf(self):
         if self._scratch is None:
             self._scratch = torch.empty(self.MAX_BWD_WAVES * self.scr_bytes, dtype=torch.uint8, device=self.device)
+        return self._scratch
+
+    def _bufs(self, nblk_chunk):
+        self._scratch_buf()
         need = nblk_chunk * self.ptiles * 2048
         if self._panels is None or self._panels.numel() < need:
             self._panels = torch.empty(need, dtype=torch.uint8, device=self.device)
@@ -173,10 +177,12 @@ class Engine:
         sdf = torch.empty(R, S, device=self.device, dtype=torch.float32)
         nrm = torch.empty(R, S, 3, device=self.device, dtype=torch.float32)
         rgb = torch.empty(R, S, 6, device=self.device, dtype=torch.float32)
+        scratch = self._scratch_buf()
         with Engine._Timed("avc_render_points_fwd", N):
             L.check(self.lib.avc_render_points_fwd(self.net, None, L.ptr(rays_o), L.ptr(rays_d), L.ptr(z), S, z.stride(0),
                                                    float(sample_dist), N, L.ptr(pk.w_f16), L.ptr(pk.tab), self.dl.offsets,
-                                                   L.ptr(sdf), L.ptr(nrm), L.ptr(rgb), L.stream()), "avc_render_points_fwd")
+                                                   L.ptr(sdf), L.ptr(nrm), L.ptr(rgb), self.MAX_BWD_WAVES, L.ptr(scratch),
+                                                   L.stream()), "avc_render_points_fwd")
         return sdf, nrm, rgb
 
     def composite_fwd(self, sdf, nrm, rgb, z, rays_o, rays_d, inv_s, sample_dist, cos_anneal, bg, bg_mode):

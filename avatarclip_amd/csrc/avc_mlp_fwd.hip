@@ -1,10 +1,10 @@
 // Forward kernels of the SDF + colour MLP (gfx950, f16 MFMA, fp32 accumulate).
 //   avc_sdf_forward       SDF only (row 0 of the last layer) -- the no-grad evaluations of the hierarchical sampler
 //                         (renderer.py:337-338,187) and of extract_fields (renderer.py:10-25)
-//   (the full point kernel avc_render_points_fwd lives in avc_mlp_v3.hip)
+//   avc_render_points_fwd sdf + normal (d sdf/dx) + 6 colour channels per sample point (renderer.py:221-232)
 #include "avc_mlp.h"
 #ifndef FWD_WPB
-#define FWD_WPB 8   // one 8-wave workgroup per CU shares every staged weight tile (see avc_mlp_v3.hip)
+#define FWD_WPB 8   // one 8-wave workgroup per CU shares every staged weight tile (LDS-DMA fill rate is the scarce resource)
 #endif
 #ifndef FWD_G
 #define FWD_G 4
@@ -42,6 +42,24 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_fwd_kernel(PointSrc ps, long
     const float sdfv = sdf_only<N>(sg, Wf, T, o, h, x0);
     if (valid && h == 0) sdf_out[oi] = sdfv;
     return;
+  }
+  FwdState<N> st;
+  st.x[0] = x0[0]; st.x[1] = x0[1]; st.x[2] = x0[2];
+  sdf_trunk<N>(sg, Wf, T, o, h, st, nxt<N, OFF_WL>(sg, Wf, o));
+  h8 feat[N::HK];
+  sdf_feature<N>(sg, Wf, T, o, h, st, feat, nxt<N, OFF_WST>(sg, Wf, o));
+  float n[3];
+  sdf_normal<N>(sg, Wf, T, o, h, st, n, nxt<N, OFF_C0>(sg, Wf, o));
+  float rgb[4];
+  color_forward<N>(sg, Wf, T, o, h, st.x, n, feat, rgb);
+  if (valid) {
+    if (h == 0) {
+      sdf_out[oi] = st.sdf;
+      normal_out[3 * oi + 0] = n[0]; normal_out[3 * oi + 1] = n[1]; normal_out[3 * oi + 2] = n[2];
+      rgb_out[6 * oi + 0] = rgb[0]; rgb_out[6 * oi + 1] = rgb[1]; rgb_out[6 * oi + 2] = rgb[2]; rgb_out[6 * oi + 3] = rgb[3];
+    } else {
+      rgb_out[6 * oi + 4] = rgb[0]; rgb_out[6 * oi + 5] = rgb[1];
+    }
   }
 }
 
@@ -89,3 +107,10 @@ extern "C" int avc_sdf_forward(int net, const float* pts, const float* rays_o, c
   return launch_fwd<0>(net, ps, npts, wf16, tab, offs, sdf_out, slot, ld_out, nullptr, nullptr, stream);
 }
 
+extern "C" int avc_render_points_fwd(int net, const float* pts, const float* rays_o, const float* rays_d,
+                                     const float* z, int S, int ldz, float sample_dist, long npts, const void* wf16,
+                                     const float* tab, const int* offs, float* sdf_out, float* normal_out,
+                                     float* rgb_out, long /*max_waves*/, void* /*scratch*/, void* stream) {
+  PointSrc ps{pts, rays_o, rays_d, z, S, ldz, pts ? 0 : 1, sample_dist};
+  return launch_fwd<1>(net, ps, npts, wf16, tab, offs, sdf_out, nullptr, 0, normal_out, rgb_out, stream);
+}

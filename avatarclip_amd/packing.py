@@ -328,7 +328,7 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
         P[name] = c
         c += nt
     P["TILES"] = c
-    scratch_ksteps = 3 * (HK + NMID * HK + SK) + 6 * HK + SK   # mirror of BwdLayout::S_KSTEPS (csrc/avc_mlp_v3.hip)
+    scratch_ksteps = (HK + NMID * HK + SK) * 2 + HK + NMID * HK + HK + NCMID * HK + HK + SK   # mirror of BwdLayout::S_KSTEPS
 
     # ---------------- weight-gradient pairs and the map of their outputs back to the dense gradient
     pairs, un_src, un_tgt, un_scale, ub_src, ub_tgt = [], [], [], [], [], []

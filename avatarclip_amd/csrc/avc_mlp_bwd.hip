@@ -9,8 +9,10 @@
 //        (two MFMAs against a 0/1 selection fragment per 32x32 block), not through LDS.
 //   avc_weight_grad       : dW[a,b] += sum_points A[p,a] B[p,b], K = points, straight from the panels.
 //
-// Activations that a later phase needs again are parked in a per-wavefront scratch slot (frag layout, L2/MALL
-// resident because the slot is reused for every block the wave processes).
+// The panels double as the activation store of the sweeps: a phase that needs h, g_a, r or ybar again reads the
+// panel tile back and un-transposes it with the same two selection MFMAs (the transposition is an involution), so
+// each activation crosses HBM once as a panel instead of once as a panel and once as a scratch copy (PMC: the
+// scratch copies were 18 % of the kernel's HBM bytes and the kernel is HBM-bound).  Only abar' lives in scratch.
 #include "avc_mlp.h"
 #ifndef BWD_WAVES_PER_EU
 #define BWD_WAVES_PER_EU 2   // 2 waves/SIMD (256 VGPRs): measured 20 % faster than 1 wave x 512 registers
@@ -55,19 +57,12 @@ struct BwdLayout {
   static constexpr int P_D2 = P_D1 + HT;            // delta2 (HT, only NC==1)
   static constexpr int P_DO = P_D2 + NC * HT;       // delta_o (1)
   static constexpr int P_TILES = P_DO + 1;
-  // scratch k-step offsets inside one wavefront slot (16-byte chunks x 64 lanes per k-step)
-  static constexpr int S_H1 = 0;
-  static constexpr int S_HM = S_H1 + N::HK;
-  static constexpr int S_HS = S_HM + NM * N::HK;
-  static constexpr int S_Q1 = S_HS + N::SK;
-  static constexpr int S_QM = S_Q1 + N::HK;
-  static constexpr int S_QS = S_QM + NM * N::HK;
-  static constexpr int S_AP1 = S_QS + N::SK;
+  // scratch k-step offsets inside one wavefront slot (16-byte chunks x 64 lanes per k-step).  Only abar' (the second-order
+  // contribution, produced in forward layer order by phase E and consumed in reverse order by phase F) is parked; every
+  // other activation a later phase needs again is read back from the panels the wave has already written (punpack).
+  static constexpr int S_AP1 = 0;
   static constexpr int S_APM = S_AP1 + N::HK;
-  static constexpr int S_R1 = S_APM + NM * N::HK;
-  static constexpr int S_R2 = S_R1 + N::HK;
-  static constexpr int S_DFEAT = S_R2 + NC * N::HK;   // ybar[1:] (bf16), parked between phases D and F
-  static constexpr int S_APS = S_DFEAT + N::HK;        // abar'_s (bf16), parked between phases E and F
+  static constexpr int S_APS = S_APM + NM * N::HK;        // abar'_s
   static constexpr int S_KSTEPS = S_APS + N::SK;
 };
 
@@ -144,6 +139,29 @@ __device__ __forceinline__ void pstore(b8* __restrict__ panel_blk, bool live, in
   }
 }
 
+// read a panel tile back into accumulator layout (lane = point, reg r <-> feature row (r&3)+8(r>>2)+4h, i.e. regs 0..7 =
+// the slots of k-step 2t, regs 8..15 = the slots of k-step 2t+1): the feature-major tile is the A operand, the same 0/1
+// selection fragments pick the point column.  Values come back exactly as stored (bf16).
+__device__ __forceinline__ facc punpack(const b8* __restrict__ panel_blk, int tile, int lane, const b8& e0, const b8& e1) {
+  const b8* src = panel_blk + (long)tile * 128 + lane;
+  const b8 k0 = src[0], k1 = src[64];
+  facc acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  acc = MF<b8>::mma(k0, e0, acc);
+  acc = MF<b8>::mma(k1, e1, acc);
+  return acc;
+}
+template <typename V>
+__device__ __forceinline__ void punpack_frags(const b8* __restrict__ panel_blk, int tile, int lane, const b8& e0, const b8& e1,
+                                              V& f0, V& f1) {
+  const facc a = punpack(panel_blk, tile, lane, e0, e1);
+  float v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = a[r];
+  acc_to_frags(v, f0, f1);
+}
+
 template <class N>
 __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long npts, const h8* __restrict__ Wf0,
                                                       const b8* __restrict__ Wb0, const float* __restrict__ T0, AvcOffsets o,
@@ -172,7 +190,6 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
     // opaque per iteration as well: otherwise every scratch address of the ~400 accesses is hoisted out of the loop
     // as a loop invariant and spilled (measured: 269 spill stores in the prologue)
     asm volatile("" : "+v"(scr0));
-    h8* scr = reinterpret_cast<h8*>(scr0);
     b8* scrb = reinterpret_cast<b8*>(scr0);
     const long blk = blk0 + wv;
     const bool live = blk < nblk;
@@ -191,82 +208,75 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
     pe_to_frags_f16(pe, x, h, pef);
     pstore<h8>(pblk, live, L::P_H0, lane, pef[0], pef[1], e0h, e1h);
     pstore<h8>(pblk, live, L::P_H0 + 1, lane, pef[2], zero_frag<h8>(), e0h, e1h);
-    // Register discipline: nothing but x, n, nbar, d_sdf survives a phase.  Every activation is parked in the wave's
-    // scratch slot (L2 resident) and re-loaded / re-computed (positional encoding) where it is needed again; this keeps
-    // each phase at "input + output + accumulators" and leaves registers for pipelining the LDS operand reads.
+    // Register discipline: nothing but x, n, nbar, d_sdf survives a phase.  Every activation goes out as a panel and is
+    // read back (punpack) / re-computed (positional encoding) where it is needed again; this keeps each phase at
+    // "input + output + accumulators" and leaves registers for pipelining the LDS operand reads.
     {
       h8 hs[N::SK];
-#define AVC_FWD_KEEP(OFFB, OUT, SCR, PT)                                                     \
+#define AVC_FWD_KEEP(OFFB, OUT, PT)                                                     \
   AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
           _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);  \
           acc_to_frags(a, OUT[2 * t], OUT[2 * t + 1]);                                        \
-          scr_store(scr, (SCR) + 2 * t, lane, OUT[2 * t]); scr_store(scr, (SCR) + 2 * t + 1, lane, OUT[2 * t + 1]); \
           pstore<h8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0h, e1h);)
       h8 h1[N::HK];
       layer_s<h8, 3, N::HT>(sg, Wf, o.v[OFF_W0], nxt<N, OFF_WM0>(sg, Wf, o), pef,
-                                   AVC_FWD_KEEP(OFF_B0, h1, L::S_H1, L::P_H1));
+                                   AVC_FWD_KEEP(OFF_B0, h1, L::P_H1));
       h8 hm0[N::HK];
       if constexpr (N::NMID == 2) {
         layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wf, o), h1,
-                                         AVC_FWD_KEEP(OFF_BM0, hm0, L::S_HM, L::P_HM));
+                                         AVC_FWD_KEEP(OFF_BM0, hm0, L::P_HM));
         h8 hm1[N::HK];
         layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wf, o), hm0,
-                                         AVC_FWD_KEEP(OFF_BM1, hm1, L::S_HM + N::HK, L::P_HM + N::HT));
+                                         AVC_FWD_KEEP(OFF_BM1, hm1, L::P_HM + N::HT));
         layer_s<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], nxt<N, OFF_WST>(sg, Wf, o), hm1,
-                                         AVC_FWD_KEEP(OFF_BS, hs, L::S_HS, L::P_HS));
+                                         AVC_FWD_KEEP(OFF_BS, hs, L::P_HS));
       } else {
         layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wf, o), h1,
-                                         AVC_FWD_KEEP(OFF_BM0, hm0, L::S_HM, L::P_HM));
+                                         AVC_FWD_KEEP(OFF_BM0, hm0, L::P_HM));
         layer_s<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], nxt<N, OFF_WST>(sg, Wf, o), hm0,
-                                         AVC_FWD_KEEP(OFF_BS, hs, L::S_HS, L::P_HS));
+                                         AVC_FWD_KEEP(OFF_BS, hs, L::P_HS));
       }
     }
     // ------------------------------------------------------------------ phase B: normal sweep (f16)
     float n[3];
     {
       h8 g_s[N::SK];
-      float w8[8];
 #pragma unroll
-      for (int s = 0; s < N::SK; ++s) {
-        load8(T + o.v[OFF_WL0_FRAG], s, h, w8);
-        const h8 hsv = scr_load(scr, L::S_HS + s, lane);
-        h8 q;
+      for (int t = 0; t < N::ST; ++t) {
+        const facc hv = punpack(pblk, L::P_HS + t, lane, e0b, e1b);
+        float w0[8], w1[8];
+        load8(T + o.v[OFF_WL0_FRAG], 2 * t, h, w0);
+        load8(T + o.v[OFF_WL0_FRAG], 2 * t + 1, h, w1);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float sg_ = sig_from_h((float)hsv[j]);
-          g_s[s][j] = (_Float16)(w8[j] * sg_);
-          q[j] = (_Float16)(w8[j] * AVC_BETA * sg_ * (1.f - sg_) * (1.f / 64.f));
+          g_s[2 * t][j] = (_Float16)(w0[j] * sig_from_h(hv[j]));
+          g_s[2 * t + 1][j] = (_Float16)(w1[j] * sig_from_h(hv[8 + j]));
         }
-        scr_store(scr, L::S_QS + s, lane, q);
+        pin2(g_s[2 * t], g_s[2 * t + 1]);
+        pstore<h8>(pblk, live, L::P_GAS + t, lane, g_s[2 * t], g_s[2 * t + 1], e0h, e1h);
       }
-#pragma unroll
-      for (int t = 0; t < N::ST; ++t) pstore<h8>(pblk, live, L::P_GAS + t, lane, g_s[2 * t], g_s[2 * t + 1], e0h, e1h);
-      // g_h(prev) = W^T g_a ; g_a(prev) = g_h * sigma(h_prev) ; q = g_h * sp''(h_prev) / 64
-#define AVC_NSTEP(OUT, SH, SQ, PT)                                                                        \
-  AVC_EPI(const h8 hv0 = scr_load(scr, (SH) + 2 * t, lane), hv1 = scr_load(scr, (SH) + 2 * t + 1, lane);   \
-          h8 q0, q1;                                                                                        \
+      // g_h(prev) = W^T g_a ; g_a(prev) = g_h * sigma(h_prev)
+#define AVC_NSTEP(OUT, PH, PT)                                                                            \
+  AVC_EPI(const facc hv = punpack(pblk, (PH) + t, lane, e0b, e1b);                                          \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                   \
-            const float s0 = sig_from_h((float)hv0[j]), s1 = sig_from_h((float)hv1[j]);                     \
-            OUT[2 * t][j] = (_Float16)(acc[j] * s0); OUT[2 * t + 1][j] = (_Float16)(acc[8 + j] * s1);        \
-            q0[j] = (_Float16)(acc[j] * AVC_BETA * s0 * (1.f - s0) * (1.f / 64.f));                          \
-            q1[j] = (_Float16)(acc[8 + j] * AVC_BETA * s1 * (1.f - s1) * (1.f / 64.f)); }                    \
+            OUT[2 * t][j] = (_Float16)(acc[j] * sig_from_h(hv[j]));                                         \
+            OUT[2 * t + 1][j] = (_Float16)(acc[8 + j] * sig_from_h(hv[8 + j])); }                           \
           pin2(OUT[2 * t], OUT[2 * t + 1]);                                                                 \
-          scr_store(scr, (SQ) + 2 * t, lane, q0); scr_store(scr, (SQ) + 2 * t + 1, lane, q1);               \
           pstore<h8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0h, e1h);)
       h8 g[N::HK];
       h8 g2[N::HK];
       if constexpr (N::NMID == 2) {
         layer_s<h8, N::SK, N::HT>(sg, Wf, o.v[OFF_WST], nxt<N, OFF_WM1T>(sg, Wf, o), g_s,
-                                         AVC_NSTEP(g, L::S_HM + N::HK, L::S_QM + N::HK, L::P_GAM + N::HT));
+                                         AVC_NSTEP(g, L::P_HM + N::HT, L::P_GAM + N::HT));
         layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1T], nxt<N, OFF_WM0T>(sg, Wf, o), g,
-                                         AVC_NSTEP(g2, L::S_HM, L::S_QM, L::P_GAM));
+                                         AVC_NSTEP(g2, L::P_HM, L::P_GAM));
         layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0T], nxt<N, OFF_W0T>(sg, Wf, o), g2,
-                                         AVC_NSTEP(g, L::S_H1, L::S_Q1, L::P_GA1));
+                                         AVC_NSTEP(g, L::P_H1, L::P_GA1));
       } else {
         layer_s<h8, N::SK, N::HT>(sg, Wf, o.v[OFF_WST], nxt<N, OFF_WM0T>(sg, Wf, o), g_s,
-                                         AVC_NSTEP(g2, L::S_HM, L::S_QM, L::P_GAM));
+                                         AVC_NSTEP(g2, L::P_HM, L::P_GAM));
         layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0T], nxt<N, OFF_W0T>(sg, Wf, o), g2,
-                                         AVC_NSTEP(g, L::S_H1, L::S_Q1, L::P_GA1));
+                                         AVC_NSTEP(g, L::P_H1, L::P_GA1));
       }
       float part[3] = {0.f, 0.f, 0.f};
       const float* wpe = T + o.v[OFF_WL0_PE] + h * 24;
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
       {
         h8 hs[N::SK];
 #pragma unroll
-        for (int s = 0; s < N::SK; ++s) hs[s] = scr_load(scr, L::S_HS + s, lane);
+        for (int t = 0; t < N::ST; ++t) punpack_frags<h8>(pblk, L::P_HS + t, lane, e0b, e1b, hs[2 * t], hs[2 * t + 1]);
         PE pe3;
         pe_compute(x, h, pe3);
         h8 pef3[3];
@@ -308,22 +318,21 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
         for (int c = 0; c < 3; ++c) { xn[0][c] = (_Float16)x[c]; xn[0][3 + c] = (_Float16)n[c]; }
       }
       pstore<h8>(pblk, live, L::P_XN, lane, xn[0], zero_frag<h8>(), e0h, e1h);
-#define AVC_RELU_KEEP(OFFB, OUT, SCR, PT)                                                    \
+#define AVC_RELU_KEEP(OFFB, OUT, PT)                                                    \
   AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
           _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r] + b[r], 0.f);   \
           acc_to_frags(a, OUT[2 * t], OUT[2 * t + 1]);                                        \
-          scr_store(scr, (SCR) + 2 * t, lane, OUT[2 * t]); scr_store(scr, (SCR) + 2 * t + 1, lane, OUT[2 * t + 1]); \
           pstore<h8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0h, e1h);)
       h8 r1[N::HK];
       h8 r2[N::HK];
       if constexpr (N::NCMID == 1) {
         layer2_s<h8, N::HK, 1, N::HT>(sg, Wf, o.v[OFF_C0], nxt<N, OFF_CM0>(sg, Wf, o), feat, xn,
-                                             AVC_RELU_KEEP(OFF_CB0, r1, L::S_R1, L::P_R1));
+                                             AVC_RELU_KEEP(OFF_CB0, r1, L::P_R1));
         layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_CM0], nxt<N, OFF_CH>(sg, Wf, o), r1,
-                                         AVC_RELU_KEEP(OFF_CBM0, r2, L::S_R2, L::P_R2));
+                                         AVC_RELU_KEEP(OFF_CBM0, r2, L::P_R2));
       } else {
         layer2_s<h8, N::HK, 1, N::HT>(sg, Wf, o.v[OFF_C0], nxt<N, OFF_CH>(sg, Wf, o), feat, xn,
-                                             AVC_RELU_KEEP(OFF_CB0, r1, L::S_R1, L::P_R1));
+                                             AVC_RELU_KEEP(OFF_CB0, r1, L::P_R1));
 #pragma unroll
         for (int s = 0; s < N::HK; ++s) r2[s] = r1[s];
       }
@@ -347,23 +356,23 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
 #pragma unroll
       for (int r = 0; r < 4; ++r) dof[0][r] = (__bf16)delta_o[r];
       pstore<b8>(pblk, live, L::P_DO, lane, dof[0], zero_frag<b8>(), e0b, e1b);
-#define AVC_RELU_BWD(OUT, SR, PT)                                                                          \
-  AVC_EPI(const h8 rv0 = scr_load(scr, (SR) + 2 * t, lane), rv1 = scr_load(scr, (SR) + 2 * t + 1, lane);    \
+#define AVC_RELU_BWD(OUT, PR, PT)                                                                          \
+  AVC_EPI(const facc rv = punpack(pblk, (PR) + t, lane, e0b, e1b);                                           \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                    \
-            OUT[2 * t][j] = (__bf16)((float)rv0[j] > 0.f ? acc[j] : 0.f);                                    \
-            OUT[2 * t + 1][j] = (__bf16)((float)rv1[j] > 0.f ? acc[8 + j] : 0.f); }                          \
+            OUT[2 * t][j] = (__bf16)(rv[j] > 0.f ? acc[j] : 0.f);                                            \
+            OUT[2 * t + 1][j] = (__bf16)(rv[8 + j] > 0.f ? acc[8 + j] : 0.f); }                              \
           pin2(OUT[2 * t], OUT[2 * t + 1]);                                                                  \
           pstore<b8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0b, e1b);)
       b8 dl[N::HK];
       b8 d1[N::HK];
       if constexpr (N::NCMID == 1) {
         layer_s<b8, 1, N::HT>(sg, Wb, o.v[OFF_CHT], nxt<N, OFF_CM0T>(sg, Wb, o), dof,
-                                     AVC_RELU_BWD(dl, L::S_R2, L::P_D2));
+                                     AVC_RELU_BWD(dl, L::P_R2, L::P_D2));
         layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_CM0T], nxt<N, OFF_C0T>(sg, Wb, o), dl,
-                                         AVC_RELU_BWD(d1, L::S_R1, L::P_D1));
+                                         AVC_RELU_BWD(d1, L::P_R1, L::P_D1));
       } else {
         layer_s<b8, 1, N::HT>(sg, Wb, o.v[OFF_CHT], nxt<N, OFF_C0T>(sg, Wb, o), dof,
-                                     AVC_RELU_BWD(d1, L::S_R1, L::P_D1));
+                                     AVC_RELU_BWD(d1, L::P_R1, L::P_D1));
       }
       // d r0 = C0^T delta1: HT feature tiles, then the [x,n] tile (rows 3,4,5 = d n)
       float dn_acc[3] = {0.f, 0.f, 0.f};
@@ -374,8 +383,6 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
             dfeat[2 * (t < N::HT ? t : 0) + 1][j] = (__bf16)acc[8 + j];
           }
           pin2(dfeat[2 * (t < N::HT ? t : 0)], dfeat[2 * (t < N::HT ? t : 0) + 1]);
-          scr_store(scrb, L::S_DFEAT + 2 * (t < N::HT ? t : 0), lane, dfeat[2 * (t < N::HT ? t : 0)]);
-          scr_store(scrb, L::S_DFEAT + 2 * (t < N::HT ? t : 0) + 1, lane, dfeat[2 * (t < N::HT ? t : 0) + 1]);
           pstore<b8>(pblk, live, L::P_DFEAT + t, lane, dfeat[2 * (t < N::HT ? t : 0)], dfeat[2 * (t < N::HT ? t : 0) + 1], e0b, e1b);
         } else {
           dn_acc[0] = acc[3]; dn_acc[1] = acc[0]; dn_acc[2] = acc[1];
@@ -418,36 +425,39 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
       }
       pstore<b8>(pblk, live, L::P_GB0, lane, gb0[0], gb0[1], e0b, e1b);
       pstore<b8>(pblk, live, L::P_GB0 + 1, lane, gb0[2], zero_frag<b8>(), e0b, e1b);
-      // gbar_a = W gbar_h(in); abar' = gbar_a * q * 64 ; gbar_h(out) = gbar_a * sigma(h_out)
-#define AVC_SECOND(OUT, SH, SQ, SAP, PT, KEEP)                                                              \
-  AVC_EPI(const h8 hv0 = scr_load(scr, (SH) + 2 * t, lane), hv1 = scr_load(scr, (SH) + 2 * t + 1, lane);    \
-          const h8 q0 = scr_load(scr, (SQ) + 2 * t, lane), q1 = scr_load(scr, (SQ) + 2 * t + 1, lane);      \
+      // gbar_a = W gbar_h(in); gbar_h(out) = gbar_a * sigma(h_out)
+      // (abar' = gbar_a * g_h * sp''(h) = gbar_a * g_a * beta (1 - sigma): g_a comes back from its panel)
+#define AVC_SECOND(OUT, PH, PG, SAP, PT)                                                                    \
+  AVC_EPI(const facc hv = punpack(pblk, (PH) + t, lane, e0b, e1b);                                           \
+          const facc gv = punpack(pblk, (PG) + t, lane, e0b, e1b);                                           \
           b8 a0, a1;                                                                                         \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                    \
-            OUT[2 * t][j] = (__bf16)(acc[j] * sig_from_h((float)hv0[j]));                                    \
-            OUT[2 * t + 1][j] = (__bf16)(acc[8 + j] * sig_from_h((float)hv1[j]));                            \
-            a0[j] = (__bf16)(acc[j] * (float)q0[j] * 64.f); a1[j] = (__bf16)(acc[8 + j] * (float)q1[j] * 64.f); } \
+            const float s0 = sig_from_h(hv[j]), s1 = sig_from_h(hv[8 + j]);                                  \
+            OUT[2 * t][j] = (__bf16)(acc[j] * s0);                                                           \
+            OUT[2 * t + 1][j] = (__bf16)(acc[8 + j] * s1);                                                   \
+            a0[j] = (__bf16)(acc[j] * gv[j] * (AVC_BETA * (1.f - s0)));                                      \
+            a1[j] = (__bf16)(acc[8 + j] * gv[8 + j] * (AVC_BETA * (1.f - s1))); }                            \
           pin2(OUT[2 * t], OUT[2 * t + 1]);                                                                  \
           scr_store(scrb, (SAP) + 2 * t, lane, a0); scr_store(scrb, (SAP) + 2 * t + 1, lane, a1);           \
           pstore<b8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0b, e1b);)
       b8 gb1[N::HK];
       layer_s<b8, 3, N::HT>(sg, Wb, o.v[OFF_W0G], nxt<N, OFF_WM0>(sg, Wb, o), gb0,
-                                   AVC_SECOND(gb1, L::S_H1, L::S_Q1, L::S_AP1, L::P_GBH1, false));
+                                   AVC_SECOND(gb1, L::P_H1, L::P_GA1, L::S_AP1, L::P_GBH1));
       b8 gbm[N::HK];
       b8 gbs[N::SK];
       if constexpr (N::NMID == 2) {
         layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wb, o), gb1,
-                                         AVC_SECOND(gbm, L::S_HM, L::S_QM, L::S_APM, L::P_GBHM, false));
+                                         AVC_SECOND(gbm, L::P_HM, L::P_GAM, L::S_APM, L::P_GBHM));
         b8 gbm1[N::HK];
         layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wb, o), gbm,
-                                         AVC_SECOND(gbm1, L::S_HM + N::HK, L::S_QM + N::HK, L::S_APM + N::HK, L::P_GBHM + N::HT, false));
+                                         AVC_SECOND(gbm1, L::P_HM + N::HT, L::P_GAM + N::HT, L::S_APM + N::HK, L::P_GBHM + N::HT));
         layer_s<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WS], nxt<N, OFF_WLT>(sg, Wb, o), gbm1,
-                                         AVC_SECOND(gbs, L::S_HS, L::S_QS, L::S_APS, L::P_GBHS, true));
+                                         AVC_SECOND(gbs, L::P_HS, L::P_GAS, L::S_APS, L::P_GBHS));
       } else {
         layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wb, o), gb1,
-                                         AVC_SECOND(gbm, L::S_HM, L::S_QM, L::S_APM, L::P_GBHM, false));
+                                         AVC_SECOND(gbm, L::P_HM, L::P_GAM, L::S_APM, L::P_GBHM));
         layer_s<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WS], nxt<N, OFF_WLT>(sg, Wb, o), gbm,
-                                         AVC_SECOND(gbs, L::S_HS, L::S_QS, L::S_APS, L::P_GBHS, true));
+                                         AVC_SECOND(gbs, L::P_HS, L::P_GAS, L::S_APS, L::P_GBHS));
       }
     }
     // ------------------------------------------------------------------ phase F: reverse sweep (ii) (bf16)
@@ -455,27 +465,27 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
       b8 as_[N::SK];
       b8 dfeat[N::HK];
 #pragma unroll
-      for (int s = 0; s < N::HK; ++s) dfeat[s] = scr_load(scrb, L::S_DFEAT + s, lane);
+      for (int t = 0; t < N::HT; ++t) punpack_frags<b8>(pblk, L::P_DFEAT + t, lane, e0b, e1b, dfeat[2 * t], dfeat[2 * t + 1]);
       // ubar[:SKIP]/sqrt2 = (W_last[1:,:]^T dfeat + W_last[0,:] d_sdf)/sqrt2 ; 1/sqrt2 is folded into both packs
       layer_s<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WLT], nxt<N, OFF_WST>(sg, Wb, o), dfeat, AVC_EPI(
         float wa[16];
         load16(T + o.v[OFF_WL0_ACC], t, h, wa);
-        const h8 hv0 = scr_load(scr, L::S_HS + 2 * t, lane), hv1 = scr_load(scr, L::S_HS + 2 * t + 1, lane);
+        const facc hv = punpack(pblk, L::P_HS + t, lane, e0b, e1b);
         const b8 ap0 = scr_load(scrb, L::S_APS + 2 * t, lane), ap1 = scr_load(scrb, L::S_APS + 2 * t + 1, lane);
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {
-          as_[2 * t][j] = (__bf16)((float)ap0[j] + (acc[j] + wa[j] * dsdfS) * sig_from_h((float)hv0[j]));
-          as_[2 * t + 1][j] = (__bf16)((float)ap1[j] + (acc[8 + j] + wa[8 + j] * dsdfS) * sig_from_h((float)hv1[j]));
+          as_[2 * t][j] = (__bf16)((float)ap0[j] + (acc[j] + wa[j] * dsdfS) * sig_from_h(hv[j]));
+          as_[2 * t + 1][j] = (__bf16)((float)ap1[j] + (acc[8 + j] + wa[8 + j] * dsdfS) * sig_from_h(hv[8 + j]));
         }
         pin2(as_[2 * t], as_[2 * t + 1]);
         pstore<b8>(pblk, live, L::P_ABS + t, lane, as_[2 * t], as_[2 * t + 1], e0b, e1b);
       ));
       // hbar(prev) = W^T abar(cur); abar(prev) = abar'(prev) + hbar * sigma(h_prev)
-#define AVC_REVERSE(OUT, SH, SAP, PT)                                                                       \
-  AVC_EPI(const h8 hv0 = scr_load(scr, (SH) + 2 * t, lane), hv1 = scr_load(scr, (SH) + 2 * t + 1, lane);    \
+#define AVC_REVERSE(OUT, PH, SAP, PT)                                                                       \
+  AVC_EPI(const facc hv = punpack(pblk, (PH) + t, lane, e0b, e1b);                                           \
           const b8 p0 = scr_load(scrb, (SAP) + 2 * t, lane), p1 = scr_load(scrb, (SAP) + 2 * t + 1, lane);  \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                    \
-            OUT[2 * t][j] = (__bf16)((float)p0[j] + acc[j] * sig_from_h((float)hv0[j]));                     \
-            OUT[2 * t + 1][j] = (__bf16)((float)p1[j] + acc[8 + j] * sig_from_h((float)hv1[j])); }           \
+            OUT[2 * t][j] = (__bf16)((float)p0[j] + acc[j] * sig_from_h(hv[j]));                             \
+            OUT[2 * t + 1][j] = (__bf16)((float)p1[j] + acc[8 + j] * sig_from_h(hv[8 + j])); }               \
           pin2(OUT[2 * t], OUT[2 * t + 1]);                                                                  \
           pstore<b8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0b, e1b);)
       b8 am[N::HK];
@@ -483,14 +493,14 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
       const Next first = nxt<N, OFF_W0>(sg, Wf0, o);   // prefetch the first tile of the next block iteration
       if constexpr (N::NMID == 2) {
         layer_s<b8, N::SK, N::HT>(sg, Wb, o.v[OFF_WST], nxt<N, OFF_WM1T>(sg, Wb, o), as_,
-                                         AVC_REVERSE(am, L::S_HM + N::HK, L::S_APM + N::HK, L::P_ABM + N::HT));
+                                         AVC_REVERSE(am, L::P_HM + N::HT, L::S_APM + N::HK, L::P_ABM + N::HT));
         layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM1T], nxt<N, OFF_WM0T>(sg, Wb, o), am,
-                                         AVC_REVERSE(am0, L::S_HM, L::S_APM, L::P_ABM));
-        layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0T], first, am0, AVC_REVERSE(am, L::S_H1, L::S_AP1, L::P_AB1));
+                                         AVC_REVERSE(am0, L::P_HM, L::S_APM, L::P_ABM));
+        layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0T], first, am0, AVC_REVERSE(am, L::P_H1, L::S_AP1, L::P_AB1));
       } else {
         layer_s<b8, N::SK, N::HT>(sg, Wb, o.v[OFF_WST], nxt<N, OFF_WM0T>(sg, Wb, o), as_,
-                                         AVC_REVERSE(am, L::S_HM, L::S_APM, L::P_ABM));
-        layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0T], first, am, AVC_REVERSE(am0, L::S_H1, L::S_AP1, L::P_AB1));
+                                         AVC_REVERSE(am, L::P_HM, L::S_APM, L::P_ABM));
+        layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0T], first, am, AVC_REVERSE(am0, L::P_H1, L::S_AP1, L::P_AB1));
       }
     }
   }

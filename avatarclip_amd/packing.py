@@ -328,7 +328,7 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
         P[name] = c
         c += nt
     P["TILES"] = c
-    scratch_ksteps = (HK + NMID * HK + SK) * 2 + HK + NMID * HK + HK + NCMID * HK + HK + SK   # mirror of BwdLayout::S_KSTEPS
+    scratch_ksteps = HK + NMID * HK + SK   # mirror of BwdLayout::S_KSTEPS (abar' only)
 
     # ---------------- weight-gradient pairs and the map of their outputs back to the dense gradient
     pairs, un_src, un_tgt, un_scale, ub_src, ub_tgt = [], [], [], [], [], []

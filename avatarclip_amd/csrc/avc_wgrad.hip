@@ -1,5 +1,5 @@
 // Weight-gradient GEMM of the NeuS MLP backward (main.py:537): dW = sum_points A^T B from the bf16 operand panels
-// written by avc_render_points_bwd (csrc/avc_mlp_v3.hip).
+// written by avc_render_points_bwd (csrc/avc_mlp_bwd.hip).
 #include "avc_common.h"
 #include "../../include/avc.h"
 
@@ -13,13 +13,12 @@
 #define WG_TB_MAX 9
 #define WG_BUF_BYTES (17 * 2048)
 
-__global__ __launch_bounds__(512) void weight_grad_kernel(const b8* __restrict__ panels, int ptiles, int pa, int ta_n, int pb,
-                                                          int tb_n, long nblk, float* __restrict__ partial,
-                                                          float* __restrict__ bias_partial, int out_elems, int bias_elems) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
+__device__ __forceinline__ void weight_grad_body(char* lds, const b8* __restrict__ panels, int ptiles, int pa, int ta_n, int pb,
+                                                 int tb_n, long nblk, float* __restrict__ partial,
+                                                 float* __restrict__ bias_partial, int out_elems, int bias_elems) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int split = blockIdx.x, nsplit = gridDim.x;
+  const int split = blockIdx.x, nsplit = gridDim.x;   // (the pair index, if any, is blockIdx.y)
   const long b0 = nblk * split / nsplit, b1 = nblk * (split + 1) / nsplit;
   const int nchunk = (ta_n + tb_n) * 2;
   auto issue = [&](long blk, int buf) {
@@ -80,6 +79,49 @@ __global__ __launch_bounds__(512) void weight_grad_kernel(const b8* __restrict__
       if (lane < 32) bias_partial[(long)split * bias_elems + wv * 32 + lane] = bsum;
     }
   }
+}
+
+__global__ __launch_bounds__(512) void weight_grad_kernel(const b8* __restrict__ panels, int ptiles, int pa, int ta_n, int pb,
+                                                          int tb_n, long nblk, float* __restrict__ partial,
+                                                          float* __restrict__ bias_partial, int out_elems, int bias_elems) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  weight_grad_body(lds, panels, ptiles, pa, ta_n, pb, tb_n, nblk, partial, bias_partial, out_elems, bias_elems);
+}
+
+// every product of one backward pass in ONE launch: blockIdx.y = pair, blockIdx.x = K-split.  Workgroups are dispatched
+// x-fastest, so the tail of one pair's splits overlaps the head of the next pair's instead of draining the chip 17 times.
+#define WG_MAX_PAIRS 24
+struct WgPairs { int v[WG_MAX_PAIRS][6]; };   // pa, ta, pb, tb, out_off, bias_off (-1 = no bias)
+__global__ __launch_bounds__(512) void weight_grad_all_kernel(const b8* __restrict__ panels, int ptiles, WgPairs pp, long nblk,
+                                                              float* __restrict__ partial, float* __restrict__ bias_partial,
+                                                              int out_elems, int bias_elems) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int* d = pp.v[blockIdx.y];
+  weight_grad_body(lds, panels, ptiles, d[0], d[1], d[2], d[3], nblk, partial + d[4], d[5] >= 0 ? bias_partial + d[5] : nullptr,
+                   out_elems, bias_elems);
+}
+
+extern "C" int avc_weight_grad_all(const void* panels, int ptiles, int npairs, const int* pairs, long nblk, float* partial,
+                                   float* bias_partial, int nsplit, int out_stride, int bias_stride, void* stream) {
+  if (nblk <= 0 || npairs <= 0) return 0;
+  if (npairs > WG_MAX_PAIRS) { avc_set_error("avc_weight_grad_all: too many pairs"); return 1; }
+  WgPairs pp;
+  for (int i = 0; i < npairs; ++i) {
+    for (int k = 0; k < 6; ++k) pp.v[i][k] = pairs[i * 6 + k];
+    if (pp.v[i][1] < 1 || pp.v[i][1] > 8 || pp.v[i][3] < 1 || pp.v[i][3] > WG_TB_MAX) {
+      avc_set_error("avc_weight_grad_all: 1 <= ta <= 8, 1 <= tb <= 9");
+      return 1;
+    }
+  }
+  if (nsplit < 1) nsplit = 1;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)weight_grad_all_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_BUF_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(weight_grad_all_kernel, dim3(nsplit, npairs), dim3(512), 2 * WG_BUF_BYTES, (hipStream_t)stream, (const b8*)panels,
+                     ptiles, pp, nblk, partial, bias_partial, out_stride, bias_stride);
+  return avc_check_launch("avc_weight_grad_all");
 }
 
 extern "C" int avc_weight_grad(const void* panels, int ptiles, int pa, int ta, int pb, int tb, long nblk, float* partial,

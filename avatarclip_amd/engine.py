@@ -74,7 +74,7 @@ class Engine:
     prof_events = []
     WG_NSPLIT = 512               # split-K workgroups per weight-gradient pair (2 per CU)
     MAX_BWD_WAVES = 2048          # 256 CUs x 4 wavefronts (one per SIMD: the backward kernel uses the full RF)
-    PANEL_BYTES_BUDGET = 12 << 30  # weight-gradient operand panels per chunk of points
+    PANEL_BYTES_BUDGET = 48 << 30  # weight-gradient operand panels per chunk of points (capped at half the free HBM)
 
     def __init__(self, spec: PK.NetSpec, device):
         if device.type != "cuda":
@@ -93,6 +93,7 @@ class Engine:
         self._panels = None
         self._partials = None
         self._bpartials = None
+        self._pairs_host = np.ascontiguousarray(np.asarray(self.dl.lay.pairs, dtype=np.int32).reshape(-1, 6))
         self._packed_key = None
         self._packed = None
 
@@ -222,7 +223,9 @@ class Engine:
         lay = self.dl.lay
         R, S = z.shape
         per_ray_blocks = S / 32.0
-        max_blocks = max(1, self.PANEL_BYTES_BUDGET // (self.ptiles * 2048))
+        have = self._panels.numel() if self._panels is not None else 0
+        budget = max(min(self.PANEL_BYTES_BUDGET, (torch.cuda.mem_get_info(self.device)[0] + have) // 2), 1 << 28)
+        max_blocks = max(1, budget // (self.ptiles * 2048))
         rays_per_chunk = max(1, int(max_blocks / per_ray_blocks) - 1)
         rays_per_chunk = min(rays_per_chunk, R)
         nblk_max = (rays_per_chunk * S + 31) // 32
@@ -248,11 +251,9 @@ class Engine:
                     self.MAX_BWD_WAVES, L.ptr(scratch), st), "avc_render_points_bwd")
             ns = max(1, min(nblk, nsplit))
             with Engine._Timed("avc_weight_grad(all pairs)", npts):
-                for (pa, ta, pb, tb, out_off, bias_off) in lay.pairs:
-                    bptr = self._bpartials.data_ptr() + bias_off * 4 if bias_off >= 0 else None
-                    L.check(self.lib.avc_weight_grad(L.ptr(panels), self.ptiles, pa, ta, pb, tb, nblk,
-                                                     self._partials.data_ptr() + out_off * 4, bptr, ns,
-                                                     self._partials.stride(0), self._bpartials.stride(0), st), "avc_weight_grad")
+                L.check(self.lib.avc_weight_grad_all(L.ptr(panels), self.ptiles, len(lay.pairs), self._pairs_host.ctypes.data,
+                                                     nblk, L.ptr(self._partials), L.ptr(self._bpartials), ns,
+                                                     self._partials.stride(0), self._bpartials.stride(0), st), "avc_weight_grad_all")
                 gout += self._partials[:ns].sum(0)
                 gbias += self._bpartials[:ns].sum(0)
         grad = torch.zeros(lay.nparam, device=self.device, dtype=torch.float32)

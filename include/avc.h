@@ -86,6 +86,11 @@ int avc_render_points_bwd(int net, const float* pts, const float* rays_o, const 
  * split s writes its slab at partial + s*out_stride (bias_partial + s*bias_stride), floats; the caller sums the slabs. */
 int avc_weight_grad(const void* panels, int ptiles, int pa, int ta, int pb, int tb, long nblk, float* partial,
                     float* bias_partial, int nsplit, int out_stride, int bias_stride, void* stream);
+/* all products of one backward pass in one launch.  pairs (host) = npairs x {pa, ta, pb, tb, out_off, bias_off}: pair i
+ * writes its tiles at partial + out_off (floats) of every split's slab and its bias sums at bias_partial + bias_off
+ * (bias_off < 0: none).  Same arithmetic as npairs calls of avc_weight_grad. */
+int avc_weight_grad_all(const void* panels, int ptiles, int npairs, const int* pairs /* host */, long nblk, float* partial,
+                        float* bias_partial, int nsplit, int out_stride, int bias_stride, void* stream);
 
 /* ---- CLIP ViT-B/32 image encoder (perceptor.encode_image, main.py:512,518,524; OpenAI clip/model.py) ----
  * y[M,N] = act(x[M,K] W^T + bias) (+ residual); W pre-packed bf16 [N/32][K/16][64][8] (lane (n,h): W[32t+n][16s+8h+j]).

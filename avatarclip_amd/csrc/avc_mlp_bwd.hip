@@ -12,7 +12,9 @@
 // The panels double as the activation store of the sweeps: a phase that needs h, g_a, r or ybar again reads the
 // panel tile back and un-transposes it with the same two selection MFMAs (the transposition is an involution), so
 // each activation crosses HBM once as a panel instead of once as a panel and once as a scratch copy (PMC: the
-// scratch copies were 18 % of the kernel's HBM bytes and the kernel is HBM-bound).  Only abar' lives in scratch.
+// scratch copies were 18 % of the kernel's HBM bytes and the kernel is HBM-bound).  The second-order term abar' is not
+// stored at all: the reverse sweep rebuilds it from the gbar_h, g_a and h panels (abar' = gbar_h g_a beta (1-s)/s).
+// ReLU masks travel from the colour forward to the colour backward as 16 bits per tile in registers.
 #include "avc_mlp.h"
 #ifndef BWD_WAVES_PER_EU
 #define BWD_WAVES_PER_EU 2   // 2 waves/SIMD (256 VGPRs): measured 20 % faster than 1 wave x 512 registers
@@ -23,6 +25,7 @@
 #ifndef BWD_WPB
 #define BWD_WPB 8   // wavefronts per workgroup: every staged weight tile is shared by 256 points (LDS-DMA fill rate is the scarce resource)
 #endif
+#define BWD_MASK_BYTES (2 * 8 * 64 * 2)   // per wavefront: 2 layers x <= 8 tiles x 64 lanes x 16 bits
 #include "../../include/avc.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -57,20 +60,10 @@ struct BwdLayout {
   static constexpr int P_D2 = P_D1 + HT;            // delta2 (HT, only NC==1)
   static constexpr int P_DO = P_D2 + NC * HT;       // delta_o (1)
   static constexpr int P_TILES = P_DO + 1;
-  // scratch k-step offsets inside one wavefront slot (16-byte chunks x 64 lanes per k-step).  Only abar' (the second-order
-  // contribution, produced in forward layer order by phase E and consumed in reverse order by phase F) is parked; every
-  // other activation a later phase needs again is read back from the panels the wave has already written (punpack).
-  static constexpr int S_AP1 = 0;
-  static constexpr int S_APM = S_AP1 + N::HK;
-  static constexpr int S_APS = S_APM + NM * N::HK;        // abar'_s
-  static constexpr int S_KSTEPS = S_APS + N::SK;
 };
 
 extern "C" int avc_bwd_panel_tiles(int net) {
   return net == AVC_NET_FULL ? BwdLayout<NetFull>::P_TILES : BwdLayout<NetSmall>::P_TILES;
-}
-extern "C" long avc_bwd_scratch_bytes_per_wave(int net) {
-  return (long)(net == AVC_NET_FULL ? BwdLayout<NetFull>::S_KSTEPS : BwdLayout<NetSmall>::S_KSTEPS) * 64 * 16;
 }
 
 template <typename P> __device__ __forceinline__ P launder(P p) {
@@ -114,8 +107,6 @@ __device__ __forceinline__ V zero_frag() {
   return z;
 }
 
-template <typename V> __device__ __forceinline__ void scr_store(V* scr, int ks, int, const V& v) { scr[ks * 64] = v; }
-template <typename V> __device__ __forceinline__ V scr_load(const V* scr, int ks, int) { return scr[ks * 64]; }
 
 // All phases run on the staged engine (avc_stage.h / layer_s): every weight tile is copied once per workgroup into
 // LDS, the epilogue of tile t-1 (activation, panel transposition, scratch parking) is issued under the MFMAs of tile t.
@@ -152,6 +143,12 @@ __device__ __forceinline__ facc punpack(const b8* __restrict__ panel_blk, int ti
   acc = MF<b8>::mma(k1, e1, acc);
   return acc;
 }
+// abar' = gbar_a g_h sp''(h) with gbar_a = gbar_h / s and g_h sp'' = g_a beta (1 - s): everything on the right is a panel
+// the wave has already written.  s -> 0 makes both gbar_h and g_a vanish; the guard keeps 0/0 out.
+__device__ __forceinline__ float second_term(float gbar_h, float g_a, float s) {
+  const float r = s > 1e-30f ? __builtin_amdgcn_rcpf(s) : 0.f;
+  return gbar_h * g_a * (AVC_BETA * (1.f - s) * r);
+}
 template <typename V>
 __device__ __forceinline__ void punpack_frags(const b8* __restrict__ panel_blk, int tile, int lane, const b8& e0, const b8& e1,
                                               V& f0, V& f1) {
@@ -166,16 +163,13 @@ template <class N>
 __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long npts, const h8* __restrict__ Wf0,
                                                       const b8* __restrict__ Wb0, const float* __restrict__ T0, AvcOffsets o,
                                                       const float* __restrict__ d_sdf, const float* __restrict__ d_normal,
-                                                      const float* __restrict__ d_rgb, b8* __restrict__ panels,
-                                                      char* __restrict__ scratch) {
+                                                      const float* __restrict__ d_rgb, b8* __restrict__ panels) {
   typedef BwdLayout<N> L;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   typedef StageT<BWD_G> ST;
   const int lane = threadIdx.x & 63, h = lane >> 5, p = lane & 31;
   const int wv = threadIdx.x >> 6;
   const long nblk = (npts + 31) >> 5;
-  const long wslot = (long)blockIdx.x * BWD_WPB + wv;
-  char* scr0 = scratch + wslot * (long)L::S_KSTEPS * 64 * 16 + lane * 16;   // this lane's 16-B column of the wave's slot
   h8 e0h, e1h; b8 e0b, e1b;
   make_sel<h8>(lane, e0h, e1h);
   make_sel<b8>(lane, e0b, e1b);
@@ -187,10 +181,6 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
     const h8* Wf = launder(Wf0);
     const b8* Wb = launder(Wb0);
     const float* T = launder(T0);
-    // opaque per iteration as well: otherwise every scratch address of the ~400 accesses is hoisted out of the loop
-    // as a loop invariant and spilled (measured: 269 spill stores in the prologue)
-    asm volatile("" : "+v"(scr0));
-    b8* scrb = reinterpret_cast<b8*>(scr0);
     const long blk = blk0 + wv;
     const bool live = blk < nblk;
     b8* pblk = panels + (live ? blk : 0) * (long)L::P_TILES * 128;
@@ -211,13 +201,26 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
     // Register discipline: nothing but x, n, nbar, d_sdf survives a phase.  Every activation goes out as a panel and is
     // read back (punpack) / re-computed (positional encoding) where it is needed again; this keeps each phase at
     // "input + output + accumulators" and leaves registers for pipelining the LDS operand reads.
+    h8 g_s[N::SK];   // g_a of the skip layer = W_last[0,:] * sigma(h_s): the seed of the normal sweep (phase B)
     {
-      h8 hs[N::SK];
 #define AVC_FWD_KEEP(OFFB, OUT, PT)                                                     \
   AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
           _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);  \
           acc_to_frags(a, OUT[2 * t], OUT[2 * t + 1]);                                        \
           pstore<h8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0h, e1h);)
+      // last trunk layer: h_s goes out as a panel only; the registers keep g_a,s
+#define AVC_FWD_LAST(OFFB, PT, PG)                                                            \
+  AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);  \
+          h8 hs0, hs1; acc_to_frags(a, hs0, hs1);                                             \
+          pstore<h8>(pblk, live, (PT) + t, lane, hs0, hs1, e0h, e1h);                         \
+          float w0[8], w1[8];                                                                 \
+          load8(T + o.v[OFF_WL0_FRAG], 2 * t, h, w0); load8(T + o.v[OFF_WL0_FRAG], 2 * t + 1, h, w1); \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                     \
+            g_s[2 * t][j] = (_Float16)(w0[j] * sig_from_h(a[j]));                             \
+            g_s[2 * t + 1][j] = (_Float16)(w1[j] * sig_from_h(a[8 + j])); }                   \
+          pin2(g_s[2 * t], g_s[2 * t + 1]);                                                   \
+          pstore<h8>(pblk, live, (PG) + t, lane, g_s[2 * t], g_s[2 * t + 1], e0h, e1h);)
       h8 h1[N::HK];
       layer_s<h8, 3, N::HT>(sg, Wf, o.v[OFF_W0], nxt<N, OFF_WM0>(sg, Wf, o), pef,
                                    AVC_FWD_KEEP(OFF_B0, h1, L::P_H1));
@@ -229,32 +232,17 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
         layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wf, o), hm0,
                                          AVC_FWD_KEEP(OFF_BM1, hm1, L::P_HM + N::HT));
         layer_s<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], nxt<N, OFF_WST>(sg, Wf, o), hm1,
-                                         AVC_FWD_KEEP(OFF_BS, hs, L::P_HS));
+                                         AVC_FWD_LAST(OFF_BS, L::P_HS, L::P_GAS));
       } else {
         layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wf, o), h1,
                                          AVC_FWD_KEEP(OFF_BM0, hm0, L::P_HM));
         layer_s<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], nxt<N, OFF_WST>(sg, Wf, o), hm0,
-                                         AVC_FWD_KEEP(OFF_BS, hs, L::P_HS));
+                                         AVC_FWD_LAST(OFF_BS, L::P_HS, L::P_GAS));
       }
     }
     // ------------------------------------------------------------------ phase B: normal sweep (f16)
     float n[3];
     {
-      h8 g_s[N::SK];
-#pragma unroll
-      for (int t = 0; t < N::ST; ++t) {
-        const facc hv = punpack(pblk, L::P_HS + t, lane, e0b, e1b);
-        float w0[8], w1[8];
-        load8(T + o.v[OFF_WL0_FRAG], 2 * t, h, w0);
-        load8(T + o.v[OFF_WL0_FRAG], 2 * t + 1, h, w1);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          g_s[2 * t][j] = (_Float16)(w0[j] * sig_from_h(hv[j]));
-          g_s[2 * t + 1][j] = (_Float16)(w1[j] * sig_from_h(hv[8 + j]));
-        }
-        pin2(g_s[2 * t], g_s[2 * t + 1]);
-        pstore<h8>(pblk, live, L::P_GAS + t, lane, g_s[2 * t], g_s[2 * t + 1], e0h, e1h);
-      }
       // g_h(prev) = W^T g_a ; g_a(prev) = g_h * sigma(h_prev)
 #define AVC_NSTEP(OUT, PH, PT)                                                                            \
   AVC_EPI(const facc hv = punpack(pblk, (PH) + t, lane, e0b, e1b);                                          \
@@ -293,6 +281,10 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
     }
     // ------------------------------------------------------------------ phase C: colour forward (f16)
     float delta_o[4];   // half 0: outputs 0..3, half 1: outputs 4,5 (delta = d_rgb * rgb (1-rgb))
+    // ReLU masks of r1 / r2: 16 bits per tile and lane (bit r = accumulator reg r), parked in a wave-private corner of LDS
+    // (registers are the scarce resource between the colour forward and its backward)
+    unsigned short* m1 = reinterpret_cast<unsigned short*>(lds + ST::LDS_BYTES + wv * BWD_MASK_BYTES) + lane;
+    unsigned short* m2 = m1 + N::HT * 64;
     {
       h8 feat[N::HK];
       {
@@ -318,21 +310,24 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
         for (int c = 0; c < 3; ++c) { xn[0][c] = (_Float16)x[c]; xn[0][3 + c] = (_Float16)n[c]; }
       }
       pstore<h8>(pblk, live, L::P_XN, lane, xn[0], zero_frag<h8>(), e0h, e1h);
-#define AVC_RELU_KEEP(OFFB, OUT, PT)                                                    \
+#define AVC_RELU_KEEP(OFFB, OUT, MSK, PT)                                                    \
   AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
-          _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r] + b[r], 0.f);   \
+          unsigned bits = 0u;                                                                 \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                    \
+            a[r] = fmaxf(acc[r] + b[r], 0.f); bits |= (a[r] > 0.f ? 1u : 0u) << r; }          \
+          MSK[t * 64] = (unsigned short)bits;                                                 \
           acc_to_frags(a, OUT[2 * t], OUT[2 * t + 1]);                                        \
           pstore<h8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0h, e1h);)
       h8 r1[N::HK];
       h8 r2[N::HK];
       if constexpr (N::NCMID == 1) {
         layer2_s<h8, N::HK, 1, N::HT>(sg, Wf, o.v[OFF_C0], nxt<N, OFF_CM0>(sg, Wf, o), feat, xn,
-                                             AVC_RELU_KEEP(OFF_CB0, r1, L::P_R1));
+                                             AVC_RELU_KEEP(OFF_CB0, r1, m1, L::P_R1));
         layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_CM0], nxt<N, OFF_CH>(sg, Wf, o), r1,
-                                         AVC_RELU_KEEP(OFF_CBM0, r2, L::P_R2));
+                                         AVC_RELU_KEEP(OFF_CBM0, r2, m2, L::P_R2));
       } else {
         layer2_s<h8, N::HK, 1, N::HT>(sg, Wf, o.v[OFF_C0], nxt<N, OFF_CH>(sg, Wf, o), feat, xn,
-                                             AVC_RELU_KEEP(OFF_CB0, r1, L::P_R1));
+                                             AVC_RELU_KEEP(OFF_CB0, r1, m1, L::P_R1));
 #pragma unroll
         for (int s = 0; s < N::HK; ++s) r2[s] = r1[s];
       }
@@ -356,23 +351,23 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
 #pragma unroll
       for (int r = 0; r < 4; ++r) dof[0][r] = (__bf16)delta_o[r];
       pstore<b8>(pblk, live, L::P_DO, lane, dof[0], zero_frag<b8>(), e0b, e1b);
-#define AVC_RELU_BWD(OUT, PR, PT)                                                                          \
-  AVC_EPI(const facc rv = punpack(pblk, (PR) + t, lane, e0b, e1b);                                           \
+#define AVC_RELU_BWD(OUT, MSK, PT)                                                                         \
+  AVC_EPI(const unsigned bits = MSK[t * 64];                                                                 \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                    \
-            OUT[2 * t][j] = (__bf16)(rv[j] > 0.f ? acc[j] : 0.f);                                            \
-            OUT[2 * t + 1][j] = (__bf16)(rv[8 + j] > 0.f ? acc[8 + j] : 0.f); }                              \
+            OUT[2 * t][j] = (__bf16)(((bits >> j) & 1u) ? acc[j] : 0.f);                                     \
+            OUT[2 * t + 1][j] = (__bf16)(((bits >> (8 + j)) & 1u) ? acc[8 + j] : 0.f); }                     \
           pin2(OUT[2 * t], OUT[2 * t + 1]);                                                                  \
           pstore<b8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0b, e1b);)
       b8 dl[N::HK];
       b8 d1[N::HK];
       if constexpr (N::NCMID == 1) {
         layer_s<b8, 1, N::HT>(sg, Wb, o.v[OFF_CHT], nxt<N, OFF_CM0T>(sg, Wb, o), dof,
-                                     AVC_RELU_BWD(dl, L::P_R2, L::P_D2));
+                                     AVC_RELU_BWD(dl, m2, L::P_D2));
         layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_CM0T], nxt<N, OFF_C0T>(sg, Wb, o), dl,
-                                         AVC_RELU_BWD(d1, L::P_R1, L::P_D1));
+                                         AVC_RELU_BWD(d1, m1, L::P_D1));
       } else {
         layer_s<b8, 1, N::HT>(sg, Wb, o.v[OFF_CHT], nxt<N, OFF_C0T>(sg, Wb, o), dof,
-                                     AVC_RELU_BWD(d1, L::P_R1, L::P_D1));
+                                     AVC_RELU_BWD(d1, m1, L::P_D1));
       }
       // d r0 = C0^T delta1: HT feature tiles, then the [x,n] tile (rows 3,4,5 = d n)
       float dn_acc[3] = {0.f, 0.f, 0.f};
@@ -426,38 +421,31 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
       pstore<b8>(pblk, live, L::P_GB0, lane, gb0[0], gb0[1], e0b, e1b);
       pstore<b8>(pblk, live, L::P_GB0 + 1, lane, gb0[2], zero_frag<b8>(), e0b, e1b);
       // gbar_a = W gbar_h(in); gbar_h(out) = gbar_a * sigma(h_out)
-      // (abar' = gbar_a * g_h * sp''(h) = gbar_a * g_a * beta (1 - sigma): g_a comes back from its panel)
-#define AVC_SECOND(OUT, PH, PG, SAP, PT)                                                                    \
+#define AVC_SECOND(OUT, PH, PT)                                                                             \
   AVC_EPI(const facc hv = punpack(pblk, (PH) + t, lane, e0b, e1b);                                           \
-          const facc gv = punpack(pblk, (PG) + t, lane, e0b, e1b);                                           \
-          b8 a0, a1;                                                                                         \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                    \
-            const float s0 = sig_from_h(hv[j]), s1 = sig_from_h(hv[8 + j]);                                  \
-            OUT[2 * t][j] = (__bf16)(acc[j] * s0);                                                           \
-            OUT[2 * t + 1][j] = (__bf16)(acc[8 + j] * s1);                                                   \
-            a0[j] = (__bf16)(acc[j] * gv[j] * (AVC_BETA * (1.f - s0)));                                      \
-            a1[j] = (__bf16)(acc[8 + j] * gv[8 + j] * (AVC_BETA * (1.f - s1))); }                            \
+            OUT[2 * t][j] = (__bf16)(acc[j] * sig_from_h(hv[j]));                                            \
+            OUT[2 * t + 1][j] = (__bf16)(acc[8 + j] * sig_from_h(hv[8 + j])); }                              \
           pin2(OUT[2 * t], OUT[2 * t + 1]);                                                                  \
-          scr_store(scrb, (SAP) + 2 * t, lane, a0); scr_store(scrb, (SAP) + 2 * t + 1, lane, a1);           \
           pstore<b8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0b, e1b);)
       b8 gb1[N::HK];
       layer_s<b8, 3, N::HT>(sg, Wb, o.v[OFF_W0G], nxt<N, OFF_WM0>(sg, Wb, o), gb0,
-                                   AVC_SECOND(gb1, L::P_H1, L::P_GA1, L::S_AP1, L::P_GBH1));
+                                   AVC_SECOND(gb1, L::P_H1, L::P_GBH1));
       b8 gbm[N::HK];
       b8 gbs[N::SK];
       if constexpr (N::NMID == 2) {
         layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wb, o), gb1,
-                                         AVC_SECOND(gbm, L::P_HM, L::P_GAM, L::S_APM, L::P_GBHM));
+                                         AVC_SECOND(gbm, L::P_HM, L::P_GBHM));
         b8 gbm1[N::HK];
         layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wb, o), gbm,
-                                         AVC_SECOND(gbm1, L::P_HM + N::HT, L::P_GAM + N::HT, L::S_APM + N::HK, L::P_GBHM + N::HT));
+                                         AVC_SECOND(gbm1, L::P_HM + N::HT, L::P_GBHM + N::HT));
         layer_s<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WS], nxt<N, OFF_WLT>(sg, Wb, o), gbm1,
-                                         AVC_SECOND(gbs, L::P_HS, L::P_GAS, L::S_APS, L::P_GBHS));
+                                         AVC_SECOND(gbs, L::P_HS, L::P_GBHS));
       } else {
         layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wb, o), gb1,
-                                         AVC_SECOND(gbm, L::P_HM, L::P_GAM, L::S_APM, L::P_GBHM));
+                                         AVC_SECOND(gbm, L::P_HM, L::P_GBHM));
         layer_s<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WS], nxt<N, OFF_WLT>(sg, Wb, o), gbm,
-                                         AVC_SECOND(gbs, L::P_HS, L::P_GAS, L::S_APS, L::P_GBHS));
+                                         AVC_SECOND(gbs, L::P_HS, L::P_GBHS));
       }
     }
     // ------------------------------------------------------------------ phase F: reverse sweep (ii) (bf16)
@@ -471,21 +459,25 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
         float wa[16];
         load16(T + o.v[OFF_WL0_ACC], t, h, wa);
         const facc hv = punpack(pblk, L::P_HS + t, lane, e0b, e1b);
-        const b8 ap0 = scr_load(scrb, L::S_APS + 2 * t, lane), ap1 = scr_load(scrb, L::S_APS + 2 * t + 1, lane);
+        const facc bv = punpack(pblk, L::P_GBHS + t, lane, e0b, e1b);
+        const facc gv = punpack(pblk, L::P_GAS + t, lane, e0b, e1b);
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {
-          as_[2 * t][j] = (__bf16)((float)ap0[j] + (acc[j] + wa[j] * dsdfS) * sig_from_h(hv[j]));
-          as_[2 * t + 1][j] = (__bf16)((float)ap1[j] + (acc[8 + j] + wa[8 + j] * dsdfS) * sig_from_h(hv[8 + j]));
+          const float s0 = sig_from_h(hv[j]), s1 = sig_from_h(hv[8 + j]);
+          as_[2 * t][j] = (__bf16)(second_term(bv[j], gv[j], s0) + (acc[j] + wa[j] * dsdfS) * s0);
+          as_[2 * t + 1][j] = (__bf16)(second_term(bv[8 + j], gv[8 + j], s1) + (acc[8 + j] + wa[8 + j] * dsdfS) * s1);
         }
         pin2(as_[2 * t], as_[2 * t + 1]);
         pstore<b8>(pblk, live, L::P_ABS + t, lane, as_[2 * t], as_[2 * t + 1], e0b, e1b);
       ));
       // hbar(prev) = W^T abar(cur); abar(prev) = abar'(prev) + hbar * sigma(h_prev)
-#define AVC_REVERSE(OUT, PH, SAP, PT)                                                                       \
+#define AVC_REVERSE(OUT, PH, PB, PG, PT)                                                                    \
   AVC_EPI(const facc hv = punpack(pblk, (PH) + t, lane, e0b, e1b);                                           \
-          const b8 p0 = scr_load(scrb, (SAP) + 2 * t, lane), p1 = scr_load(scrb, (SAP) + 2 * t + 1, lane);  \
+          const facc bv = punpack(pblk, (PB) + t, lane, e0b, e1b);                                           \
+          const facc gv = punpack(pblk, (PG) + t, lane, e0b, e1b);                                           \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                    \
-            OUT[2 * t][j] = (__bf16)((float)p0[j] + acc[j] * sig_from_h(hv[j]));                             \
-            OUT[2 * t + 1][j] = (__bf16)((float)p1[j] + acc[8 + j] * sig_from_h(hv[8 + j])); }               \
+            const float s0 = sig_from_h(hv[j]), s1 = sig_from_h(hv[8 + j]);                                  \
+            OUT[2 * t][j] = (__bf16)(second_term(bv[j], gv[j], s0) + acc[j] * s0);                           \
+            OUT[2 * t + 1][j] = (__bf16)(second_term(bv[8 + j], gv[8 + j], s1) + acc[8 + j] * s1); }         \
           pin2(OUT[2 * t], OUT[2 * t + 1]);                                                                  \
           pstore<b8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0b, e1b);)
       b8 am[N::HK];
@@ -493,14 +485,14 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
       const Next first = nxt<N, OFF_W0>(sg, Wf0, o);   // prefetch the first tile of the next block iteration
       if constexpr (N::NMID == 2) {
         layer_s<b8, N::SK, N::HT>(sg, Wb, o.v[OFF_WST], nxt<N, OFF_WM1T>(sg, Wb, o), as_,
-                                         AVC_REVERSE(am, L::P_HM + N::HT, L::S_APM + N::HK, L::P_ABM + N::HT));
+                                         AVC_REVERSE(am, L::P_HM + N::HT, L::P_GBHM + N::HT, L::P_GAM + N::HT, L::P_ABM + N::HT));
         layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM1T], nxt<N, OFF_WM0T>(sg, Wb, o), am,
-                                         AVC_REVERSE(am0, L::P_HM, L::S_APM, L::P_ABM));
-        layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0T], first, am0, AVC_REVERSE(am, L::P_H1, L::S_AP1, L::P_AB1));
+                                         AVC_REVERSE(am0, L::P_HM, L::P_GBHM, L::P_GAM, L::P_ABM));
+        layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0T], first, am0, AVC_REVERSE(am, L::P_H1, L::P_GBH1, L::P_GA1, L::P_AB1));
       } else {
         layer_s<b8, N::SK, N::HT>(sg, Wb, o.v[OFF_WST], nxt<N, OFF_WM0T>(sg, Wb, o), as_,
-                                         AVC_REVERSE(am, L::P_HM, L::S_APM, L::P_ABM));
-        layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0T], first, am, AVC_REVERSE(am0, L::P_H1, L::S_AP1, L::P_AB1));
+                                         AVC_REVERSE(am, L::P_HM, L::P_GBHM, L::P_GAM, L::P_ABM));
+        layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0T], first, am, AVC_REVERSE(am0, L::P_H1, L::P_GBH1, L::P_GA1, L::P_AB1));
       }
     }
   }
@@ -509,7 +501,7 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
 extern "C" int avc_render_points_bwd(int net, const float* pts, const float* rays_o, const float* rays_d, const float* z,
                                      int S, int ldz, float sample_dist, long npts, const void* wf16, const void* wbf16,
                                      const float* tab, const int* offs, const float* d_sdf, const float* d_normal,
-                                     const float* d_rgb, void* panels, long max_waves, float* scratch, void* stream) {
+                                     const float* d_rgb, void* panels, long max_waves, void* stream) {
   if (npts <= 0) return 0;
   AvcOffsets o;
   for (int k = 0; k < OFF_COUNT; ++k) o.v[k] = offs[k];
@@ -521,7 +513,7 @@ extern "C" int avc_render_points_bwd(int net, const float* pts, const float* ray
   int grid = (int)(ngroups < maxg ? ngroups : maxg);
   if (grid < 1) grid = 1;
   hipStream_t s = (hipStream_t)stream;
-  const int lds_bytes = StageT<BWD_G>::LDS_BYTES;
+  const int lds_bytes = StageT<BWD_G>::LDS_BYTES + BWD_WPB * BWD_MASK_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)mlp_bwd_kernel<NetFull>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -530,10 +522,10 @@ extern "C" int avc_render_points_bwd(int net, const float* pts, const float* ray
   }
   if (net == AVC_NET_FULL)
     hipLaunchKernelGGL((mlp_bwd_kernel<NetFull>), dim3(grid), dim3(64 * BWD_WPB), lds_bytes, s, ps, npts, (const h8*)wf16, (const b8*)wbf16,
-                       tab, o, d_sdf, d_normal, d_rgb, (b8*)panels, (char*)scratch);
+                       tab, o, d_sdf, d_normal, d_rgb, (b8*)panels);
   else if (net == AVC_NET_SMALL)
     hipLaunchKernelGGL((mlp_bwd_kernel<NetSmall>), dim3(grid), dim3(64 * BWD_WPB), lds_bytes, s, ps, npts, (const h8*)wf16, (const b8*)wbf16,
-                       tab, o, d_sdf, d_normal, d_rgb, (b8*)panels, (char*)scratch);
+                       tab, o, d_sdf, d_normal, d_rgb, (b8*)panels);
   else { avc_set_error("unknown net id"); return 1; }
   return avc_check_launch("avc_render_points_bwd");
 }

@@ -110,7 +110,7 @@ extern "C" int avc_sdf_forward(int net, const float* pts, const float* rays_o, c
 extern "C" int avc_render_points_fwd(int net, const float* pts, const float* rays_o, const float* rays_d,
                                      const float* z, int S, int ldz, float sample_dist, long npts, const void* wf16,
                                      const float* tab, const int* offs, float* sdf_out, float* normal_out,
-                                     float* rgb_out, long /*max_waves*/, void* /*scratch*/, void* stream) {
+                                     float* rgb_out, void* stream) {
   PointSrc ps{pts, rays_o, rays_d, z, S, ldz, pts ? 0 : 1, sample_dist};
   return launch_fwd<1>(net, ps, npts, wf16, tab, offs, sdf_out, nullptr, 0, normal_out, rgb_out, stream);
 }

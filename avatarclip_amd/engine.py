@@ -87,9 +87,6 @@ class Engine:
         assert self.lib.avc_num_offsets() == PK.OFF_COUNT
         self.ptiles = self.lib.avc_bwd_panel_tiles(self.net)
         assert self.ptiles == self.dl.lay.panel["TILES"], "panel layout mismatch between packing.py and avc_mlp_bwd.hip"
-        self.scr_bytes = self.lib.avc_bwd_scratch_bytes_per_wave(self.net)
-        assert self.scr_bytes == self.dl.lay.scratch_ksteps * 1024
-        self._scratch = None
         self._panels = None
         self._partials = None
         self._bpartials = None
@@ -130,17 +127,11 @@ class Engine:
     def pack(self, flatP: torch.Tensor) -> Packed:
         return Packed(self.dl, flatP)
 
-    def _scratch_buf(self):
-        if self._scratch is None:
-            self._scratch = torch.empty(self.MAX_BWD_WAVES * self.scr_bytes, dtype=torch.uint8, device=self.device)
-        return self._scratch
-
     def _bufs(self, nblk_chunk):
-        self._scratch_buf()
         need = nblk_chunk * self.ptiles * 2048
         if self._panels is None or self._panels.numel() < need:
             self._panels = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._scratch, self._panels
+        return self._panels
 
     # ------------------------------------------------------------------ forward launches
     def sdf_rays(self, pk: Packed, rays_o, rays_d, z, sdf_out=None, slot=None, ld_out=0):
@@ -178,12 +169,10 @@ class Engine:
         sdf = torch.empty(R, S, device=self.device, dtype=torch.float32)
         nrm = torch.empty(R, S, 3, device=self.device, dtype=torch.float32)
         rgb = torch.empty(R, S, 6, device=self.device, dtype=torch.float32)
-        scratch = self._scratch_buf()
         with Engine._Timed("avc_render_points_fwd", N):
             L.check(self.lib.avc_render_points_fwd(self.net, None, L.ptr(rays_o), L.ptr(rays_d), L.ptr(z), S, z.stride(0),
                                                    float(sample_dist), N, L.ptr(pk.w_f16), L.ptr(pk.tab), self.dl.offsets,
-                                                   L.ptr(sdf), L.ptr(nrm), L.ptr(rgb), self.MAX_BWD_WAVES, L.ptr(scratch),
-                                                   L.stream()), "avc_render_points_fwd")
+                                                   L.ptr(sdf), L.ptr(nrm), L.ptr(rgb), L.stream()), "avc_render_points_fwd")
         return sdf, nrm, rgb
 
     def composite_fwd(self, sdf, nrm, rgb, z, rays_o, rays_d, inv_s, sample_dist, cos_anneal, bg, bg_mode):
@@ -229,7 +218,7 @@ class Engine:
         rays_per_chunk = max(1, int(max_blocks / per_ray_blocks) - 1)
         rays_per_chunk = min(rays_per_chunk, R)
         nblk_max = (rays_per_chunk * S + 31) // 32
-        scratch, panels = self._bufs(nblk_max)
+        panels = self._bufs(nblk_max)
         gout = torch.zeros(lay.gout_size, device=self.device, dtype=torch.float32)
         gbias = torch.zeros(max(lay.gbias_size, 1), device=self.device, dtype=torch.float32)
         nsplit = self.WG_NSPLIT
@@ -248,7 +237,7 @@ class Engine:
                     z.data_ptr() + r0 * z.stride(0) * esz, S, z.stride(0), float(sample_dist), npts, L.ptr(pk.w_f16),
                     L.ptr(pk.w_bf16), L.ptr(pk.tab), self.dl.offsets, d_sdf.data_ptr() + r0 * S * esz,
                     d_n.data_ptr() + r0 * S * 3 * esz, d_rgb.data_ptr() + r0 * S * 6 * esz, L.ptr(panels),
-                    self.MAX_BWD_WAVES, L.ptr(scratch), st), "avc_render_points_bwd")
+                    self.MAX_BWD_WAVES, st), "avc_render_points_bwd")
             ns = max(1, min(nblk, nsplit))
             with Engine._Timed("avc_weight_grad(all pairs)", npts):
                 L.check(self.lib.avc_weight_grad_all(L.ptr(panels), self.ptiles, len(lay.pairs), self._pairs_host.ctypes.data,

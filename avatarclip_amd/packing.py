@@ -182,7 +182,6 @@ class Layout:
     un_scale: np.ndarray
     ub_src: np.ndarray
     ub_tgt: np.ndarray
-    scratch_ksteps: int = 0
 
 
 def _elem(pbase, name, shape, row, col, transposed):
@@ -328,7 +327,6 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
         P[name] = c
         c += nt
     P["TILES"] = c
-    scratch_ksteps = HK + NMID * HK + SK   # mirror of BwdLayout::S_KSTEPS (abar' only)
 
     # ---------------- weight-gradient pairs and the map of their outputs back to the dense gradient
     pairs, un_src, un_tgt, un_scale, ub_src, ub_tgt = [], [], [], [], [], []
@@ -420,8 +418,7 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
                   idx32=np.concatenate(idx32), scale32=np.concatenate(sc32), offsets=offsets, panel=P, pairs=pairs,
                   gout_size=gout[0], gbias_size=gbias[0],
                   un_src=np.concatenate(un_src), un_tgt=np.concatenate(un_tgt), un_scale=np.concatenate(un_scale),
-                  ub_src=np.asarray(ub_src, np.int64), ub_tgt=np.asarray(ub_tgt, np.int64),
-                  scratch_ksteps=scratch_ksteps)
+                  ub_src=np.asarray(ub_src, np.int64), ub_tgt=np.asarray(ub_tgt, np.int64))
 
 
 def layout_for(spec: NetSpec) -> Layout:

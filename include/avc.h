@@ -47,8 +47,7 @@ int avc_upsample_step(const float* rays_o, const float* rays_d, const float* z_i
  * section mid-points of z[R,S] (or at pts[N,3]): sdf[N], normal[N,3] (= d sdf/dx), rgb[N,6] = sigmoid([rgb ; extra]). */
 int avc_render_points_fwd(int net, const float* pts, const float* rays_o, const float* rays_d, const float* z,
                           int S, int ldz, float sample_dist, long npts, const void* wf16, const float* tab,
-                          const int* offs /* host */, float* sdf_out, float* normal_out, float* rgb_out, long max_waves,
-                          void* scratch /* max_waves * avc_bwd_scratch_bytes_per_wave(net) */, void* stream);
+                          const int* offs /* host */, float* sdf_out, float* normal_out, float* rgb_out, void* stream);
 
 /* NeuS alpha + compositing of render_core (renderer.py:234-286), one wavefront per ray.
  * bg_mode 0: none, 1: bg[3] shared, 2: bg[R] grey per ray (main.py:387-415); background is composited into
@@ -72,13 +71,13 @@ int avc_composite_bwd(const float* sdf, const float* normal, const float* rgb, c
  * SDFNetwork.gradient, fields.py:96-107; main.py:537).  Recomputes the forward, runs the second-order and the
  * reverse sweep and writes the bf16 operand panels of every weight-gradient product to `panels`
  * (avc_bwd_panel_tiles(net) tiles of 2 KiB per 32-point block); avc_weight_grad then contracts them over the
- * points.  `scratch` holds max_waves * avc_bwd_scratch_bytes_per_wave(net) bytes. */
+ * points.  The kernel keeps no other state in memory: what a later sweep needs again it reads back from the panels.
+ * max_waves bounds the resident grid (persistent workgroups of 8 wavefronts). */
 int avc_bwd_panel_tiles(int net);
-long avc_bwd_scratch_bytes_per_wave(int net);
 int avc_render_points_bwd(int net, const float* pts, const float* rays_o, const float* rays_d, const float* z,
                           int S, int ldz, float sample_dist, long npts, const void* wf16, const void* wbf16,
                           const float* tab, const int* offs /* host */, const float* d_sdf, const float* d_normal,
-                          const float* d_rgb, void* panels, long max_waves, float* scratch, void* stream);
+                          const float* d_rgb, void* panels, long max_waves, void* stream);
 
 /* partial[split][ta,tb,64,16] = sum over the split's share of `nblk` 32-point blocks of A-panel tile (pa+ta) x B-panel
  * tile (pb+tb), K = points; lane (n,h), reg r of tile (ta,tb) is dW[32 ta + (r&3)+8(r>>2)+4h][32 tb + n].

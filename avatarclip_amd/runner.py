@@ -344,11 +344,17 @@ class Runner:
         else:
             text = self.encoded_text
         img = texture_shading if self.texture_cast_light else extra_color_fine
-        enc = self.perceptor.encode_image(self.clip_preprocess(img.reshape(H, W, 3)))
+        if self.add_no_texture:
+            # main.py:512 and :524 encode the two images in two calls; the encoder treats batch entries independently, so
+            # one B=2 pass gives the same two embeddings with every frozen ViT weight streamed once instead of twice
+            enc_both = self.perceptor.encode_image(torch.cat([self.clip_preprocess(img.reshape(H, W, 3)),
+                                                              self.clip_preprocess(rand_shading_rgb.reshape(H, W, 3))], dim=0))
+            enc, enc2 = enc_both[0:1], enc_both[1:2]
+        else:
+            enc = self.perceptor.encode_image(self.clip_preprocess(img.reshape(H, W, 3)))
         cosine = torch.cosine_similarity(torch.mean(enc, dim=0), torch.mean(text, dim=0), dim=0)
         loss = color_fine_loss + eikonal_loss * self.igr_weight + mask_loss * self.mask_weight + (1.0 - cosine) * self.clip_weight
         if self.add_no_texture:
-            enc2 = self.perceptor.encode_image(self.clip_preprocess(rand_shading_rgb.reshape(H, W, 3)))
             cosine_shading = torch.cosine_similarity(torch.mean(enc2, dim=0), torch.mean(text, dim=0), dim=0)
             loss = loss + (1.0 - cosine_shading) * self.clip_weight
         self.optimizer.zero_grad()

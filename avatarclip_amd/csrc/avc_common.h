@@ -42,6 +42,7 @@ enum AvcOff {
   OFF_B0, OFF_BM0, OFF_BM1, OFF_BS, OFF_BL, OFF_BL0,     // packed biases (acc order), BL0 = scalar sdf bias
   OFF_WL0_ACC, OFF_WL0_FRAG, OFF_WL0_PE,                 // row 0 of the last layer / sqrt2 in acc order, frag order, pe-slot order
   OFF_CB0, OFF_CBM0, OFF_CBH,
+  OFF_TAB_END,                                           // length of the fp32 table (floats)
   OFF_COUNT
 };
 struct AvcOffsets { int v[OFF_COUNT]; };
@@ -87,18 +88,53 @@ __device__ __forceinline__ facc tile_gemm2(const V* __restrict__ wp, const V (&i
   return acc;
 }
 
+// Pointers that went through a register-laundering asm lose their address space: hipcc then emits FLAT loads/stores, which
+// count on vmcnt AND lgkmcnt (every "wait for my LDS operands" also waits for them) and are ordered against LDS traffic.
+// Everything the kernels touch through such pointers is global memory -- say so.
+#define AVC_GLOBAL __attribute__((address_space(1)))
+template <typename T> __device__ __forceinline__ const AVC_GLOBAL T* as_global(const T* p) {
+  return (const AVC_GLOBAL T*)(p);
+}
+template <typename T> __device__ __forceinline__ AVC_GLOBAL T* as_global(T* p) { return (AVC_GLOBAL T*)(p); }
+
 // packed per-tile fp32 table [tile][half][16] -> this lane's 16 values
 __device__ __forceinline__ void load16(const float* __restrict__ tab, int t, int h, float (&out)[16]) {
-  const f4* p = reinterpret_cast<const f4*>(tab + (t * 2 + h) * 16);
+  const AVC_GLOBAL f4* p = as_global(reinterpret_cast<const f4*>(tab + (t * 2 + h) * 16));
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     f4 v = p[q];
     out[4 * q + 0] = v[0]; out[4 * q + 1] = v[1]; out[4 * q + 2] = v[2]; out[4 * q + 3] = v[3];
   }
 }
+// the same from the copy of the table the forward kernels keep in LDS (tab_to_lds): a global load in an epilogue sits behind
+// the LDS-DMA of the next weight group in the in-order vmcnt queue and stalls the wave until that whole group has landed
+// (ablation: 22-30 % of the forward kernels' time); ds_read has its own counter and ~100 cycles of latency
+#define AVC_LDS __attribute__((address_space(3)))
+typedef const AVC_LDS float* lds_tab_t;
+__device__ __forceinline__ void load16(lds_tab_t tab, int t, int h, float (&out)[16]) {
+  const AVC_LDS f4* p = reinterpret_cast<const AVC_LDS f4*>(tab + (t * 2 + h) * 16);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f4 v = p[q];
+    out[4 * q + 0] = v[0]; out[4 * q + 1] = v[1]; out[4 * q + 2] = v[2]; out[4 * q + 3] = v[3];
+  }
+}
+__device__ __forceinline__ void load8(lds_tab_t tab, int s, int h, float (&out)[8]) {
+  const AVC_LDS f4* p = reinterpret_cast<const AVC_LDS f4*>(tab + (s * 2 + h) * 8);
+  f4 a = p[0], b = p[1];
+  out[0] = a[0]; out[1] = a[1]; out[2] = a[2]; out[3] = a[3];
+  out[4] = b[0]; out[5] = b[1]; out[6] = b[2]; out[7] = b[3];
+}
+#define AVC_TAB_LDS_BYTES 10240   // fp32 table of the full net: 2292 floats
+// copy the fp32 table into LDS (all threads of the workgroup; the caller synchronises before the first use)
+__device__ __forceinline__ lds_tab_t tab_to_lds(char* lds_dst, const float* __restrict__ tab, int n) {
+  AVC_LDS float* d = (AVC_LDS float*)lds_dst;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) d[i] = tab[i];
+  return (lds_tab_t)d;
+}
 // frag-order fp32 table [kstep][half][8] -> this lane's 8 values
 __device__ __forceinline__ void load8(const float* __restrict__ tab, int s, int h, float (&out)[8]) {
-  const f4* p = reinterpret_cast<const f4*>(tab + (s * 2 + h) * 8);
+  const AVC_GLOBAL f4* p = as_global(reinterpret_cast<const f4*>(tab + (s * 2 + h) * 8));
   f4 a = p[0], b = p[1];
   out[0] = a[0]; out[1] = a[1]; out[2] = a[2]; out[3] = a[3];
   out[4] = b[0]; out[5] = b[1]; out[6] = b[2]; out[7] = b[3];

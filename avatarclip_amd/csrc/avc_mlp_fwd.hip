@@ -11,12 +11,11 @@
 #endif
 #include "../../include/avc.h"
 
-template <class N, int MODE>
-__global__ __launch_bounds__(64 * FWD_WPB) void mlp_fwd_kernel(PointSrc ps, long npts, const h8* __restrict__ Wf,
-                                                                       const float* __restrict__ T, AvcOffsets o,
-                                                                       float* __restrict__ sdf_out, const int* __restrict__ slot,
-                                                                       int ld_out, float* __restrict__ normal_out,
-                                                                       float* __restrict__ rgb_out) {
+template <class N>
+__global__ __launch_bounds__(64 * FWD_WPB) void mlp_sdf_kernel(PointSrc ps, long npts, const h8* __restrict__ Wf,
+                                                               const float* __restrict__ T, AvcOffsets o,
+                                                               float* __restrict__ sdf_out, const int* __restrict__ slot,
+                                                               int ld_out) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   typedef StageT<FWD_G> ST;
   const int lane = threadIdx.x & 63;
@@ -24,13 +23,14 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_fwd_kernel(PointSrc ps, long
   const int p = lane & 31;
   // one wavefront per 32-point block; the wavefronts of a workgroup share every weight tile through LDS, so no wave
   // may leave early: blocks past the end are clamped to the last point and only their stores are suppressed.
-  // (No persistent loop: LICM would hoist the loop-invariant weight traffic and spill.)
   const long blk = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   long i = blk * 32 + p;
   const bool valid = i < npts;
   if (!valid) i = npts - 1;
   ST sg = stage_init<ST::G>(lds);
   stage_issue(sg, nxt<N, OFF_W0>(sg, Wf, o), 0);
+  const lds_tab_t Tl = tab_to_lds(lds + ST::LDS_BYTES, T, o.v[OFF_TAB_END]);
+  __syncthreads();
   float x0[3];
   fetch_point(ps, i, x0);
   long oi = i;
@@ -38,29 +38,198 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_fwd_kernel(PointSrc ps, long
     const long ray = i / ps.S;
     oi = ray * ld_out + slot[i];
   }
-  if (MODE == 0) {
-    const float sdfv = sdf_only<N>(sg, Wf, T, o, h, x0);
-    if (valid && h == 0) sdf_out[oi] = sdfv;
-    return;
-  }
-  FwdState<N> st;
-  st.x[0] = x0[0]; st.x[1] = x0[1]; st.x[2] = x0[2];
-  sdf_trunk<N>(sg, Wf, T, o, h, st, nxt<N, OFF_WL>(sg, Wf, o));
-  h8 feat[N::HK];
-  sdf_feature<N>(sg, Wf, T, o, h, st, feat, nxt<N, OFF_WST>(sg, Wf, o));
-  float n[3];
-  sdf_normal<N>(sg, Wf, T, o, h, st, n, nxt<N, OFF_C0>(sg, Wf, o));
-  float rgb[4];
-  color_forward<N>(sg, Wf, T, o, h, st.x, n, feat, rgb);
-  if (valid) {
-    if (h == 0) {
-      sdf_out[oi] = st.sdf;
-      normal_out[3 * oi + 0] = n[0]; normal_out[3 * oi + 1] = n[1]; normal_out[3 * oi + 2] = n[2];
-      rgb_out[6 * oi + 0] = rgb[0]; rgb_out[6 * oi + 1] = rgb[1]; rgb_out[6 * oi + 2] = rgb[2]; rgb_out[6 * oi + 3] = rgb[3];
-    } else {
-      rgb_out[6 * oi + 4] = rgb[0]; rgb_out[6 * oi + 5] = rgb[1];
+  const float sdfv = sdf_only<N>(sg, Wf, Tl, o, h, x0);
+  if (valid && h == 0) sdf_out[oi] = sdfv;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// avc_render_points_fwd: sdf + normal + colour.  The normal sweep needs sigma(h_l) of every trunk layer in REVERSE order;
+// keeping h1..h_s of 32 points in registers is 248 VGPRs of state on top of the working set, which the first version of
+// this kernel paid for with 331 spilled registers -- PMC: 114 GB of scratch traffic per 16.8 M points, i.e. the kernel
+// was bound by its own spills (HBM), not by MFMA.  Here the three H-wide activations are parked EXPLICITLY in a
+// per-wavefront slot (frag layout, one coalesced 1-KiB store per k-step, 64 KiB per 32 points incl. the feature vector
+// instead of ~217 KiB of spill traffic; 2048 slots = 134 MB, inside the 256 MB Infinity Cache) and read back tile by tile in the epilogues of the
+// sweep; h_s never leaves the registers (it is consumed at once by g_a,s and by the feature layer).
+// Persistent workgroups (the slot is reused for every block a wave processes).
+// ---------------------------------------------------------------------------------------------------------------
+template <class N>
+struct FwdScratch {
+  static constexpr int S_H1 = 0;
+  static constexpr int S_HM = S_H1 + N::HK;
+  static constexpr int S_FEAT = S_HM + N::NMID * N::HK;   // feature vector, parked across the normal sweep
+  static constexpr int S_KSTEPS = S_FEAT + N::HK;
+};
+template <typename P> __device__ __forceinline__ P launder_ptr(P p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+template <class N>
+__global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, long npts, const h8* __restrict__ Wf0,
+                                                                  const float* __restrict__ T0, AvcOffsets o,
+                                                                  float* __restrict__ sdf_out, float* __restrict__ normal_out,
+                                                                  float* __restrict__ rgb_out, char* __restrict__ scratch) {
+  typedef FwdScratch<N> L;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  typedef StageT<FWD_G> ST;
+  const int lane = threadIdx.x & 63, h = lane >> 5, p = lane & 31;
+  const int wv = threadIdx.x >> 6;
+  const long nblk = (npts + 31) >> 5;
+  const long wslot = (long)blockIdx.x * FWD_WPB + wv;
+  char* scr0 = scratch + wslot * (long)L::S_KSTEPS * 1024 + lane * 16;
+  ST sg = stage_init<FWD_G>(lds);
+  stage_issue(sg, nxt<N, OFF_W0>(sg, Wf0, o), 0);
+  const lds_tab_t T = tab_to_lds(lds + ST::LDS_BYTES, T0, o.v[OFF_TAB_END]);
+  __syncthreads();
+  for (long blk0 = (long)blockIdx.x * FWD_WPB; blk0 < nblk; blk0 += (long)gridDim.x * FWD_WPB) {
+    // opaque per iteration: otherwise LICM hoists the loop-invariant addresses out of the loop and spills them
+    const h8* Wf = launder_ptr(Wf0);
+    asm volatile("" : "+v"(scr0));
+    AVC_GLOBAL h8* scr = as_global(reinterpret_cast<h8*>(scr0));
+    const long blk = blk0 + wv;
+    long i = blk * 32 + p;
+    const bool valid = i < npts;
+    if (!valid) i = npts - 1;
+    float x[3];
+    fetch_point(ps, i, x);
+    // ---------------------------------------------------------------- trunk
+    float sdf;
+    h8 g_s[N::SK];
+    {
+      h8 hs[N::SK];
+      float part = 0.f;
+      PE pe;
+      pe_compute(x, h, pe);
+      {
+        const auto wpe = T + o.v[OFF_WL0_PE] + h * 24;
+#pragma unroll
+        for (int q = 0; q < 24; ++q) part += wpe[q] * pe.v[q];
+      }
+      h8 pef[3];
+      pe_to_frags_f16(pe, x, h, pef);
+#define AVC_F_PARK(OFFB, OUT, SCR)                                                           \
+  AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);  \
+          acc_to_frags(a, OUT[2 * t], OUT[2 * t + 1]);                                        \
+          scr[((SCR) + 2 * t) * 64] = OUT[2 * t]; scr[((SCR) + 2 * t + 1) * 64] = OUT[2 * t + 1];)
+#define AVC_F_LAST(OFFB)                                                                      \
+  AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);  \
+          load16(T + o.v[OFF_WL0_ACC], t, h, b);                                              \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) part += b[r] * a[r];                 \
+          acc_to_frags(a, hs[2 * t], hs[2 * t + 1]);                                          \
+          float w0[8], w1[8];                                                                 \
+          load8(T + o.v[OFF_WL0_FRAG], 2 * t, h, w0); load8(T + o.v[OFF_WL0_FRAG], 2 * t + 1, h, w1); \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                     \
+            g_s[2 * t][j] = (_Float16)(w0[j] * sig_from_h(a[j]));                             \
+            g_s[2 * t + 1][j] = (_Float16)(w1[j] * sig_from_h(a[8 + j])); }                   \
+          pin2(g_s[2 * t], g_s[2 * t + 1]);)
+      {
+        h8 h1[N::HK];
+        layer_s<h8, 3, N::HT>(sg, Wf, o.v[OFF_W0], nxt<N, OFF_WM0>(sg, Wf, o), pef, AVC_F_PARK(OFF_B0, h1, L::S_H1));
+        h8 hm0[N::HK];
+        if constexpr (N::NMID == 2) {
+          layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wf, o), h1, AVC_F_PARK(OFF_BM0, hm0, L::S_HM));
+          h8 hm1[N::HK];
+          layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wf, o), hm0,
+                                    AVC_F_PARK(OFF_BM1, hm1, L::S_HM + N::HK));
+          layer_s<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], nxt<N, OFF_WL>(sg, Wf, o), hm1, AVC_F_LAST(OFF_BS));
+        } else {
+          layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wf, o), h1, AVC_F_PARK(OFF_BM0, hm0, L::S_HM));
+          layer_s<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], nxt<N, OFF_WL>(sg, Wf, o), hm0, AVC_F_LAST(OFF_BS));
+        }
+      }
+      sdf = xhalf_sum(part) + T[o.v[OFF_BL0]];
+      // feature = rows 1..H of the last layer on u = [h_s ; pe]/sqrt2 (1/sqrt2 folded into the packed weights)
+      layer2_s<h8, N::SK, 3, N::HT>(sg, Wf, o.v[OFF_WL], nxt<N, OFF_WST>(sg, Wf, o), hs, pef, AVC_EPI(
+        float b[16], a[16];
+        load16(T + o.v[OFF_BL], t, h, b);
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = acc[r] + b[r];
+        h8 f0, f1;
+        acc_to_frags(a, f0, f1);
+        scr[(L::S_FEAT + 2 * t) * 64] = f0; scr[(L::S_FEAT + 2 * t + 1) * 64] = f1;
+      ));
+    }
+    // ---------------------------------------------------------------- normal sweep: g_h(prev) = W^T g_a ; g_a(prev) = g_h sigma(h_prev)
+    float n[3];
+    {
+#define AVC_F_NSTEP(OUT, SH)                                                                              \
+  AVC_EPI(const h8 hv0 = scr[((SH) + 2 * t) * 64], hv1 = scr[((SH) + 2 * t + 1) * 64];                     \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                   \
+            OUT[2 * t][j] = (_Float16)(acc[j] * sig_from_h((float)hv0[j]));                                 \
+            OUT[2 * t + 1][j] = (_Float16)(acc[8 + j] * sig_from_h((float)hv1[j])); }                       \
+          pin2(OUT[2 * t], OUT[2 * t + 1]);)
+      h8 g[N::HK];
+      h8 g2[N::HK];
+      if constexpr (N::NMID == 2) {
+        layer_s<h8, N::SK, N::HT>(sg, Wf, o.v[OFF_WST], nxt<N, OFF_WM1T>(sg, Wf, o), g_s, AVC_F_NSTEP(g, L::S_HM + N::HK));
+        layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1T], nxt<N, OFF_WM0T>(sg, Wf, o), g, AVC_F_NSTEP(g2, L::S_HM));
+        layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0T], nxt<N, OFF_W0T>(sg, Wf, o), g2, AVC_F_NSTEP(g, L::S_H1));
+      } else {
+        layer_s<h8, N::SK, N::HT>(sg, Wf, o.v[OFF_WST], nxt<N, OFF_WM0T>(sg, Wf, o), g_s, AVC_F_NSTEP(g2, L::S_HM));
+        layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0T], nxt<N, OFF_W0T>(sg, Wf, o), g2, AVC_F_NSTEP(g, L::S_H1));
+      }
+      float part[3] = {0.f, 0.f, 0.f};
+      const auto wpe = T + o.v[OFF_WL0_PE] + h * 24;
+      PE pe2;
+      pe_compute(x, h, pe2);
+      layer_s<h8, N::HK, 2>(sg, Wf, o.v[OFF_W0T], nxt<N, OFF_C0>(sg, Wf, o), g, AVC_EPI(
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {
+          const int q = 16 * t + r;
+          if (q < 24) part[q % 3] += pe2.d[q] * (acc[r] + wpe[q]);
+        }
+      ));
+#pragma unroll
+      for (int c = 0; c < 3; ++c) n[c] = xhalf_sum(part[c]);
+    }
+    // ---------------------------------------------------------------- colour MLP (fields.py:154-185)
+    float rgb[4];
+    {
+      h8 xn[1];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xn[0][j] = (_Float16)0.f;
+      if (h == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { xn[0][c] = (_Float16)x[c]; xn[0][3 + c] = (_Float16)n[c]; }
+      }
+      h8 feat[N::HK];
+#pragma unroll
+      for (int s = 0; s < N::HK; ++s) feat[s] = scr[(L::S_FEAT + s) * 64];
+#define AVC_F_RELU(OFFB, OUT)                                                                 \
+  AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r] + b[r], 0.f);   \
+          acc_to_frags(a, OUT[2 * t], OUT[2 * t + 1]);)
+      h8 r1[N::HK];
+      h8 r2[N::HK];
+      if constexpr (N::NCMID == 1) {
+        layer2_s<h8, N::HK, 1, N::HT>(sg, Wf, o.v[OFF_C0], nxt<N, OFF_CM0>(sg, Wf, o), feat, xn, AVC_F_RELU(OFF_CB0, r1));
+        layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_CM0], nxt<N, OFF_CH>(sg, Wf, o), r1, AVC_F_RELU(OFF_CBM0, r2));
+      } else {
+        layer2_s<h8, N::HK, 1, N::HT>(sg, Wf, o.v[OFF_C0], nxt<N, OFF_CH>(sg, Wf, o), feat, xn, AVC_F_RELU(OFF_CB0, r1));
+#pragma unroll
+        for (int s = 0; s < N::HK; ++s) r2[s] = r1[s];
+      }
+      // the first tile of the next block iteration is prefetched under the head layer
+      layer_s<h8, N::HK, 1>(sg, Wf, o.v[OFF_CH], nxt<N, OFF_W0>(sg, Wf0, o), r2, AVC_EPI(
+        float b[16];
+        load16(T + o.v[OFF_CBH], 0, h, b);
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) rgb[r] = sigmoidf_(acc[r] + b[r]);
+      ));
+    }
+    if (valid) {
+      if (h == 0) {
+        sdf_out[i] = sdf;
+        normal_out[3 * i + 0] = n[0]; normal_out[3 * i + 1] = n[1]; normal_out[3 * i + 2] = n[2];
+        rgb_out[6 * i + 0] = rgb[0]; rgb_out[6 * i + 1] = rgb[1]; rgb_out[6 * i + 2] = rgb[2]; rgb_out[6 * i + 3] = rgb[3];
+      } else {
+        rgb_out[6 * i + 4] = rgb[0]; rgb_out[6 * i + 5] = rgb[1];
+      }
     }
   }
+}
+
+extern "C" long avc_fwd_scratch_bytes_per_wave(int net) {
+  return (long)(net == AVC_NET_FULL ? FwdScratch<NetFull>::S_KSTEPS : FwdScratch<NetSmall>::S_KSTEPS) * 1024;
 }
 
 static int grid_for(long npts, int waves_per_block, int max_blocks) {
@@ -71,46 +240,77 @@ static int grid_for(long npts, int waves_per_block, int max_blocks) {
   return (int)g;
 }
 
-template <int MODE>
-static int launch_fwd(int net, PointSrc ps, long npts, const void* wf, const float* tab, const int* offs,
-                      float* sdf_out, const int* slot, int ld_out, float* normal_out, float* rgb_out, void* stream) {
+static int check_tab(const int* offs) {
+  if (offs[OFF_TAB_END] * 4 > AVC_TAB_LDS_BYTES) { avc_set_error("fp32 table does not fit its LDS window"); return 1; }
+  return 0;
+}
+
+static int launch_sdf(int net, PointSrc ps, long npts, const void* wf, const float* tab, const int* offs,
+                      float* sdf_out, const int* slot, int ld_out, void* stream) {
   if (npts <= 0) return 0;
+  if (check_tab(offs)) return 1;
   AvcOffsets o;
   for (int k = 0; k < OFF_COUNT; ++k) o.v[k] = offs[k];
   hipStream_t s = (hipStream_t)stream;
   const int wpb = FWD_WPB;   // wavefronts per workgroup
   const int grid = grid_for(npts, wpb, 0x7fffffff);
-  const int lds_bytes = StageT<FWD_G>::LDS_BYTES;
+  const int lds_bytes = StageT<FWD_G>::LDS_BYTES + AVC_TAB_LDS_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)mlp_fwd_kernel<NetFull, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    hipFuncSetAttribute((const void*)mlp_fwd_kernel<NetSmall, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipFuncSetAttribute((const void*)mlp_sdf_kernel<NetFull>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipFuncSetAttribute((const void*)mlp_sdf_kernel<NetSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     attr_set = true;
   }
   if (net == AVC_NET_FULL)
-    hipLaunchKernelGGL((mlp_fwd_kernel<NetFull, MODE>), dim3(grid), dim3(64 * wpb), lds_bytes, s, ps, npts, (const h8*)wf, tab, o,
-                       sdf_out, slot, ld_out, normal_out, rgb_out);
+    hipLaunchKernelGGL((mlp_sdf_kernel<NetFull>), dim3(grid), dim3(64 * wpb), lds_bytes, s, ps, npts, (const h8*)wf, tab, o,
+                       sdf_out, slot, ld_out);
   else if (net == AVC_NET_SMALL)
-    hipLaunchKernelGGL((mlp_fwd_kernel<NetSmall, MODE>), dim3(grid), dim3(64 * wpb), lds_bytes, s, ps, npts, (const h8*)wf, tab, o,
-                       sdf_out, slot, ld_out, normal_out, rgb_out);
+    hipLaunchKernelGGL((mlp_sdf_kernel<NetSmall>), dim3(grid), dim3(64 * wpb), lds_bytes, s, ps, npts, (const h8*)wf, tab, o,
+                       sdf_out, slot, ld_out);
   else {
     avc_set_error("unknown net id");
     return 1;
   }
-  return avc_check_launch(MODE ? "avc_render_points_fwd" : "avc_sdf_forward");
+  return avc_check_launch("avc_sdf_forward");
 }
 
 extern "C" int avc_sdf_forward(int net, const float* pts, const float* rays_o, const float* rays_d, const float* z,
                                int S, int ldz, long npts, const void* wf16, const float* tab, const int* offs,
                                float* sdf_out, const int* slot, int ld_out, void* stream) {
   PointSrc ps{pts, rays_o, rays_d, z, S, ldz, 0, 0.f};
-  return launch_fwd<0>(net, ps, npts, wf16, tab, offs, sdf_out, slot, ld_out, nullptr, nullptr, stream);
+  return launch_sdf(net, ps, npts, wf16, tab, offs, sdf_out, slot, ld_out, stream);
 }
 
 extern "C" int avc_render_points_fwd(int net, const float* pts, const float* rays_o, const float* rays_d,
                                      const float* z, int S, int ldz, float sample_dist, long npts, const void* wf16,
                                      const float* tab, const int* offs, float* sdf_out, float* normal_out,
-                                     float* rgb_out, void* stream) {
+                                     float* rgb_out, long max_waves, void* scratch, void* stream) {
+  if (npts <= 0) return 0;
+  if (!scratch) { avc_set_error("avc_render_points_fwd: scratch == NULL"); return 1; }
+  if (check_tab(offs)) return 1;
   PointSrc ps{pts, rays_o, rays_d, z, S, ldz, pts ? 0 : 1, sample_dist};
-  return launch_fwd<1>(net, ps, npts, wf16, tab, offs, sdf_out, nullptr, 0, normal_out, rgb_out, stream);
+  AvcOffsets o;
+  for (int k = 0; k < OFF_COUNT; ++k) o.v[k] = offs[k];
+  long maxg = max_waves / FWD_WPB;
+  if (maxg < 1) maxg = 1;
+  const int grid = grid_for(npts, FWD_WPB, (int)(maxg < 0x7fffffff ? maxg : 0x7fffffff));
+  const int lds_bytes = StageT<FWD_G>::LDS_BYTES + AVC_TAB_LDS_BYTES;
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)mlp_render_kernel<NetFull>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipFuncSetAttribute((const void*)mlp_render_kernel<NetSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    attr_set = true;
+  }
+  if (net == AVC_NET_FULL)
+    hipLaunchKernelGGL((mlp_render_kernel<NetFull>), dim3(grid), dim3(64 * FWD_WPB), lds_bytes, s, ps, npts, (const h8*)wf16, tab, o,
+                       sdf_out, normal_out, rgb_out, (char*)scratch);
+  else if (net == AVC_NET_SMALL)
+    hipLaunchKernelGGL((mlp_render_kernel<NetSmall>), dim3(grid), dim3(64 * FWD_WPB), lds_bytes, s, ps, npts, (const h8*)wf16, tab, o,
+                       sdf_out, normal_out, rgb_out, (char*)scratch);
+  else {
+    avc_set_error("unknown net id");
+    return 1;
+  }
+  return avc_check_launch("avc_render_points_fwd");
 }

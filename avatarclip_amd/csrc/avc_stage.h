@@ -48,6 +48,9 @@ __device__ __forceinline__ StageT<G> stage_init(char* lds) {
 template <class ST>
 __device__ __forceinline__ void stage_issue(const ST& st, const Next& nx, int buf) {
   if (!nx.ptr) return;
+#ifdef AVC_ABL_NODMA   // timing ablation only (results are garbage)
+  return;
+#endif
   const char* g = reinterpret_cast<const char*>(nx.ptr);
   char* dst = st.lds + buf * ST::BUF_BYTES;
   for (int c = st.wave; c < nx.chunks; c += st.nw) {
@@ -61,16 +64,43 @@ __device__ __forceinline__ void stage_issue(const ST& st, const Next& nx, int bu
 // round trip per MFMA, seen in the ISA of every kernel built on this engine).  pinN() makes a batch of fragments opaque at a
 // program point, so the reads of the whole batch are issued back to back and the MFMA chain then runs at the matrix pipe's
 // own rate; the second half's reads are already in flight while the first half's MFMAs execute.
+// (not volatile: a volatile asm is ordered against every memory operation and every other volatile asm, which would pin the
+// epilogue of the previous tile -- its loads, stores and its own pin2 -- behind the last batch of the MFMA chain)
 template <typename V>
-__device__ __forceinline__ void pin4(V& a, V& b, V& c, V& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+__device__ __forceinline__ void pin4(V& a, V& b, V& c, V& d) { asm("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+
+// Interleave request for one tile step: the scheduling region holds the MFMA chain of tile t and the (independent) epilogue
+// of tile t-1.  Left alone, hipcc emits the 16 dependent MFMAs back to back (the wave stalls ~32 cycles on each) and then
+// ~150 VALU instructions with the matrix pipe idle; both wavefronts of a SIMD run in lockstep between the group barriers,
+// so MFMA time and VALU time ADD (measured: forward kernel = MFMA 32 us + VALU 32 us + LDS 31 us + DMA 24 us per round).
+// One MFMA followed by a slice of VALU work, KS times, lets the epilogue run in the shadow of the chain.
+#ifndef AVC_VALU_PER_MFMA
+#define AVC_VALU_PER_MFMA 10
+#endif
+template <int KS>
+__device__ __forceinline__ void interleave_mfma_valu() {
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // 1 MFMA
+    __builtin_amdgcn_sched_group_barrier(0x002, AVC_VALU_PER_MFMA, 0);   // then a slice of VALU
+  }
+}
+#ifndef AVC_LDS_AHEAD
+#define AVC_LDS_AHEAD 8   // A fragments in flight ahead of the MFMA chain (x4 VGPRs each)
+#endif
 template <typename V, int KS>
 __device__ __forceinline__ facc mma_chain_lds(const V* __restrict__ a_lds /* lane's chunk of k-step 0 */, const V (&in)[KS], facc acc) {
+  // rolling prefetch: AVC_LDS_AHEAD fragments are requested up front, every group of 4 MFMAs is preceded by the requests
+  // of the group AVC_LDS_AHEAD further on.  (All KS at once costs 4*KS VGPRs -- 64 for a 256-wide layer -- and pushed the
+  // sweeps over the 256-register budget: ~140 spilled registers in every kernel built on this engine.)
   V a[KS];
 #pragma unroll
-  for (int s = 0; s < KS; ++s) a[s] = a_lds[s * 64];
+  for (int s = 0; s < KS && s < AVC_LDS_AHEAD; ++s) a[s] = a_lds[s * 64];
 #pragma unroll
   for (int s = 0; s < KS; s += 4) {
     if (s + 3 < KS) pin4(a[s], a[s + 1], a[s + 2], a[s + 3]);
+#pragma unroll
+    for (int k = s + AVC_LDS_AHEAD; k < s + AVC_LDS_AHEAD + 4 && k < KS; ++k) a[k] = a_lds[k * 64];
 #pragma unroll
     for (int k = s; k < s + 4 && k < KS; ++k) acc = MF<V>::mma(a[k], in[k], acc);
   }

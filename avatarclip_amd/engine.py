@@ -73,6 +73,7 @@ class Engine:
     PROFILE = False               # bench.py: record (name, points, start_event, end_event) per kernel launch group
     prof_events = []
     WG_NSPLIT = 512               # split-K workgroups per weight-gradient pair (2 per CU)
+    MAX_FWD_WAVES = 2048          # persistent grid of avc_render_points_fwd: 256 CUs x one 8-wave workgroup
     MAX_BWD_WAVES = 2048          # 256 CUs x 4 wavefronts (one per SIMD: the backward kernel uses the full RF)
     PANEL_BYTES_BUDGET = 48 << 30  # weight-gradient operand panels per chunk of points (capped at half the free HBM)
 
@@ -87,6 +88,8 @@ class Engine:
         assert self.lib.avc_num_offsets() == PK.OFF_COUNT
         self.ptiles = self.lib.avc_bwd_panel_tiles(self.net)
         assert self.ptiles == self.dl.lay.panel["TILES"], "panel layout mismatch between packing.py and avc_mlp_bwd.hip"
+        self.fwd_scr_bytes = self.lib.avc_fwd_scratch_bytes_per_wave(self.net)
+        self._fwd_scratch = None
         self._panels = None
         self._partials = None
         self._bpartials = None
@@ -169,10 +172,13 @@ class Engine:
         sdf = torch.empty(R, S, device=self.device, dtype=torch.float32)
         nrm = torch.empty(R, S, 3, device=self.device, dtype=torch.float32)
         rgb = torch.empty(R, S, 6, device=self.device, dtype=torch.float32)
+        if self._fwd_scratch is None:
+            self._fwd_scratch = torch.empty(self.MAX_FWD_WAVES * self.fwd_scr_bytes, dtype=torch.uint8, device=self.device)
         with Engine._Timed("avc_render_points_fwd", N):
             L.check(self.lib.avc_render_points_fwd(self.net, None, L.ptr(rays_o), L.ptr(rays_d), L.ptr(z), S, z.stride(0),
                                                    float(sample_dist), N, L.ptr(pk.w_f16), L.ptr(pk.tab), self.dl.offsets,
-                                                   L.ptr(sdf), L.ptr(nrm), L.ptr(rgb), L.stream()), "avc_render_points_fwd")
+                                                   L.ptr(sdf), L.ptr(nrm), L.ptr(rgb), self.MAX_FWD_WAVES, L.ptr(self._fwd_scratch),
+                                                   L.stream()), "avc_render_points_fwd")
         return sdf, nrm, rgb
 
     def composite_fwd(self, sdf, nrm, rgb, z, rays_o, rays_d, inv_s, sample_dist, cos_anneal, bg, bg_mode):

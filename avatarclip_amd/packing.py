@@ -316,6 +316,7 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
     if NCMID == 1:
         table("OFF_CBM0", bias_tab("col.b1", H, HT))
     table("OFF_CBH", bias_tab("col.bh", 6, 1))
+    offsets[OFF["OFF_TAB_END"]] = cur32[0]
 
     # ---------------- panel layout (mirror of BwdLayout in csrc/avc_mlp_bwd.hip)
     P = {}

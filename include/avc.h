@@ -47,7 +47,11 @@ int avc_upsample_step(const float* rays_o, const float* rays_d, const float* z_i
  * section mid-points of z[R,S] (or at pts[N,3]): sdf[N], normal[N,3] (= d sdf/dx), rgb[N,6] = sigmoid([rgb ; extra]). */
 int avc_render_points_fwd(int net, const float* pts, const float* rays_o, const float* rays_d, const float* z,
                           int S, int ldz, float sample_dist, long npts, const void* wf16, const float* tab,
-                          const int* offs /* host */, float* sdf_out, float* normal_out, float* rgb_out, void* stream);
+                          const int* offs /* host */, float* sdf_out, float* normal_out, float* rgb_out, long max_waves,
+                          void* scratch /* max_waves * avc_fwd_scratch_bytes_per_wave(net) bytes */, void* stream);
+/* bytes of the per-wavefront slot in which avc_render_points_fwd parks the trunk activations between the forward and the
+ * normal sweep (persistent workgroups of 8 wavefronts; max_waves bounds the resident grid) */
+long avc_fwd_scratch_bytes_per_wave(int net);
 
 /* NeuS alpha + compositing of render_core (renderer.py:234-286), one wavefront per ray.
  * bg_mode 0: none, 1: bg[3] shared, 2: bg[R] grey per ray (main.py:387-415); background is composited into

@@ -16,10 +16,14 @@ def t(fn, reps=5):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-for npts in [2**14, 2**16, 2**17, 2**18, 2**20, 2**22]:
+sizes = [int(a) for a in sys.argv[1:]] or [2**14, 2**16, 2**17, 2**18, 2**20, 2**22]
+for npts in sizes:
     R = npts // 64
     ro = torch.randn(R, 3, device=dev) * 0.1; rd = torch.nn.functional.normalize(torch.randn(R, 3, device=dev), dim=-1)
     z = torch.sort(torch.rand(R, 64, device=dev) * 2, dim=-1)[0].contiguous()
     ms_sdf = t(lambda: eng.sdf_rays(pk, ro, rd, z))
     ms_fwd = t(lambda: eng.points_fwd(pk, ro, rd, z, 2 / 32))
+    dsdf = torch.randn(R, 64, device=dev); dn = torch.randn(R, 64, 3, device=dev) * 0.1; drgb = torch.randn(R, 64, 6, device=dev) * 0.1
+    ms_bwd = t(lambda: eng.points_bwd(pk, ro, rd, z, 2 / 32, dsdf, dn, drgb), reps=3)
+    print("npts %8d  points_bwd+weight_grad %8.3f ms" % (npts, ms_bwd), flush=True)
     print("npts %8d  sdf-only %8.3f ms (%.1f TF/s)   points_fwd %8.3f ms (%.1f TF/s)" % (npts, ms_sdf, npts * 393728 / ms_sdf / 1e9, ms_fwd, npts * 1186816 / ms_fwd / 1e9), flush=True)

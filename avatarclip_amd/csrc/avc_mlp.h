@@ -69,7 +69,8 @@ __device__ __forceinline__ Next nxt(const ST&, const void* blob, const AvcOffset
   typedef TileInfo<N, OFF> TI;
   Next n;
   n.ptr = reinterpret_cast<const char*>(blob) + (long)o.v[OFF] * 2;
-  n.chunks = TI::KS * (TI::NT < ST::G ? TI::NT : ST::G);
+  constexpr int G = ST::template group<TI::KS>();
+  n.chunks = TI::KS * (TI::NT < G ? TI::NT : G);
   return n;
 }
 __device__ __forceinline__ Next no_next() { Next n; n.ptr = nullptr; n.chunks = 0; return n; }
@@ -99,7 +100,7 @@ __device__ __forceinline__ void dephase(const ST& st) {
 template <typename V, int KS, int NT, class ST, typename Epi>
 __device__ __forceinline__ void layer_s(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&in)[KS],
                                         Epi&& epi) {
-  constexpr int G = ST::G;
+  constexpr int G = ST::template group<KS>();
   constexpr int NG = (NT + G - 1) / G;
   facc prev;
 #pragma unroll
@@ -132,8 +133,8 @@ __device__ __forceinline__ void layer_s(ST& st, const V* __restrict__ blob, int 
 template <typename V, int KA, int KB, int NT, class ST, typename Epi>
 __device__ __forceinline__ void layer2_s(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&ina)[KA],
                                          const V (&inb)[KB], Epi&& epi) {
-  constexpr int G = ST::G;
   constexpr int KS = KA + KB;
+  constexpr int G = ST::template group<KS>();
   constexpr int NG = (NT + G - 1) / G;
   facc prev;
 #pragma unroll

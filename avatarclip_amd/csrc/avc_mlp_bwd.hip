@@ -175,12 +175,14 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
   make_sel<b8>(lane, e0b, e1b);
   ST sg = stage_init<BWD_G>(lds);
   stage_issue(sg, nxt<N, OFF_W0>(sg, Wf0, o), 0);
+  // the fp32 table lives in LDS: a global load in an epilogue would queue behind the LDS-DMA of the next weight group
+  const lds_tab_t T = tab_to_lds(lds + ST::LDS_BYTES + BWD_WPB * BWD_MASK_BYTES, T0, o.v[OFF_TAB_END]);
+  __syncthreads();
 
   // every wavefront of a workgroup runs the same number of iterations (workgroup-uniform loop bound)
   for (long blk0 = (long)blockIdx.x * BWD_WPB; blk0 < nblk; blk0 += (long)gridDim.x * BWD_WPB) {
     const h8* Wf = launder(Wf0);
     const b8* Wb = launder(Wb0);
-    const float* T = launder(T0);
     const long blk = blk0 + wv;
     const bool live = blk < nblk;
     b8* pblk = panels + (live ? blk : 0) * (long)L::P_TILES * 128;
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
                                          AVC_NSTEP(g, L::P_H1, L::P_GA1));
       }
       float part[3] = {0.f, 0.f, 0.f};
-      const float* wpe = T + o.v[OFF_WL0_PE] + h * 24;
+      const auto wpe = T + o.v[OFF_WL0_PE] + h * 24;
       PE pe2;
       pe_compute(x, h, pe2);
       layer_s<h8, N::HK, 2>(sg, Wf, o.v[OFF_W0T], nxt<N, OFF_WL>(sg, Wf, o), g, AVC_EPI(
@@ -513,7 +515,8 @@ extern "C" int avc_render_points_bwd(int net, const float* pts, const float* ray
   int grid = (int)(ngroups < maxg ? ngroups : maxg);
   if (grid < 1) grid = 1;
   hipStream_t s = (hipStream_t)stream;
-  const int lds_bytes = StageT<BWD_G>::LDS_BYTES + BWD_WPB * BWD_MASK_BYTES;
+  const int lds_bytes = StageT<BWD_G>::LDS_BYTES + BWD_WPB * BWD_MASK_BYTES + AVC_TAB_LDS_BYTES;
+  if (offs[OFF_TAB_END] * 4 > AVC_TAB_LDS_BYTES) { avc_set_error("fp32 table does not fit its LDS window"); return 1; }
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)mlp_bwd_kernel<NetFull>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);

@@ -15,7 +15,9 @@
 #pragma once
 #include "avc_common.h"
 
-#define STAGE_TILE_BYTES (17 * 1024)   // largest tile: 17 k-steps x 1 KiB (K = skip features + PE slots / H + [x,n])
+#define STAGE_TILE_BYTES (16 * 1024)   // a 256-wide tile: 16 k-steps x 1 KiB; the 17-k-step layers (K = skip features + PE slots,
+                                        // H + [x,n]) go in groups of G-1 tiles so that a buffer is G x 16 KiB (LDS also holds the
+                                        // fp32 table and, in the backward kernel, the ReLU masks)
 
 struct Next {          // the group that follows in the static tile sequence
   const void* ptr;     // nullptr = nothing follows
@@ -27,6 +29,8 @@ struct StageT {
   static constexpr int G = G_;
   static constexpr int BUF_BYTES = G_ * STAGE_TILE_BYTES;
   static constexpr int LDS_BYTES = 2 * G_ * STAGE_TILE_BYTES;
+  // tiles per group of a layer whose tiles have KS k-steps
+  template <int KS> static constexpr int group() { return (KS * 1024 * G_ <= BUF_BYTES) ? G_ : BUF_BYTES / (KS * 1024); }
   char* lds;   // LDS_BYTES, 16-byte aligned
   int par;     // buffer holding the group that is consumed next
   int wave;    // wave index in the workgroup (SGPR)

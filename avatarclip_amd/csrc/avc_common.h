@@ -142,6 +142,9 @@ __device__ __forceinline__ void load8(const float* __restrict__ tab, int s, int 
 
 __device__ __forceinline__ float softplus2(float t) {
   // H = S * Softplus_beta100(t / S)  (nn.Softplus(beta=100), fields.py:68) in base-2 units; raw v_exp_f32 / v_log_f32
+#ifdef AVC_ABL_CHEAPACT   // timing ablation only (what the transcendentals cost)
+  return fmaxf(t, 0.f);
+#endif
   const float e = __builtin_amdgcn_exp2f(-fabsf(t));
   return fmaxf(t, 0.f) + __builtin_amdgcn_logf(1.f + e);
 }

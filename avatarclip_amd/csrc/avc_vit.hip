@@ -28,6 +28,9 @@ __global__ __launch_bounds__(256) void vit_linear_kernel(const float* __restrict
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
   const b8* wp = Wp + ((long)t * KS) * 64 + lane;
+  // 4 k-steps per trip: the loop is a chain of dependent L2/HBM round trips (12..48 trips per wave at ~1.5 us each was the
+  // whole 46 us of a call); unrolled, the loads of four k-steps are in flight together
+#pragma unroll 4
   for (int s = s0; s < s1; ++s) {
     const b8 w = wp[(long)s * 64];
 #pragma unroll

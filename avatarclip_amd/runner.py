@@ -473,9 +473,11 @@ def _gaussian_blur(x, ksize, sigma):
         r = torch.arange(k, device=x.device, dtype=x.dtype) - (k - 1) / 2
         w = torch.exp(-0.5 * (r / sigma) ** 2)
         return w / w.sum()
-    kx, ky = k1d(ksize[0]), k1d(ksize[1])
-    C = x.shape[1]
+    kx, ky = k1d(ksize[0]).tolist(), k1d(ksize[1]).tolist()
+    H, W = x.shape[-2:]
     x = F.pad(x, (ksize[0] // 2, ksize[0] // 2, ksize[1] // 2, ksize[1] // 2), mode="reflect")
-    x = F.conv2d(x, kx.view(1, 1, 1, -1).repeat(C, 1, 1, 1), groups=C)
-    x = F.conv2d(x, ky.view(1, 1, -1, 1).repeat(C, 1, 1, 1), groups=C)
+    # 5 + 9 shifted multiply-adds instead of F.conv2d: MIOpen answers a [1,1,H,W] depthwise convolution with its naive
+    # kernel (1.4 ms per call in the profile, 2 % of a step)
+    x = sum(w * x[..., :, k:k + W] for k, w in enumerate(kx))
+    x = sum(w * x[..., k:k + H, :] for k, w in enumerate(ky))
     return x

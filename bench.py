@@ -95,9 +95,10 @@ model {
     return ConfigFactory.parse_string(text)
 
 
-def cpu_baseline(spp, rays=1024, iters=2, max_threads=16):
+def cpu_baseline(spp, rays=4096, iters=2, max_threads=16):
     """The CPU oracle (port of the reference's algorithm, oracle/neus_oracle.py + clip_vit_oracle.py) on a bounded
-    sample of the same workload: `rays` rays of one view, full-size nets, full step incl. 2 CLIP passes and Adam."""
+    sample of the same workload: `rays` rays of one view (64x64 = BASELINE config 1's view), full-size nets, full step incl.
+    2 CLIP passes and Adam; 1 warm-up + `iters` timed iterations (about 20 s of CPU work)."""
     from oracle import neus_oracle as O, clip_vit_oracle as C
     from avatarclip_amd import fields
     # a bounded number of host threads: the many small ops of the reference path oversubscribe badly beyond ~16 threads

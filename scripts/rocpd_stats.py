@@ -1,6 +1,8 @@
 """Summarise a rocprofv3 rocpd sqlite database: per-kernel count / total / average duration."""
-import sqlite3, sys
+import glob, os, sqlite3, sys
 def main(path, limit=30):
+    if os.path.isdir(path):   # a rocprofv3 -d directory: take the (first) database below it
+        path = sorted(glob.glob(os.path.join(path, "**", "*.db"), recursive=True))[0]
     c = sqlite3.connect(path)
     tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
     kd = [t for t in tabs if t.startswith('rocpd_kernel_dispatch')][0]

@@ -129,3 +129,23 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(lib, n), n
     lib.avc_version.restype = ctypes.c_int
     assert lib.avc_version() >= 1
+
+
+def test_gaussian_blur_matches_depthwise_convolution():
+    """runner._gaussian_blur (shifted multiply-adds) == the separable depthwise convolution of torchvision's GaussianBlur"""
+    import torch.nn.functional as F
+    from avatarclip_amd.runner import _gaussian_blur
+    torch.manual_seed(3)
+    x = torch.rand(1, 1, 40, 36)
+    ksize, sigma = (5, 9), 1.3
+
+    def k1d(k):
+        r = torch.arange(k, dtype=x.dtype) - (k - 1) / 2
+        w = torch.exp(-0.5 * (r / sigma) ** 2)
+        return w / w.sum()
+    ref = F.pad(x, (2, 2, 4, 4), mode="reflect")
+    ref = F.conv2d(ref, k1d(5).view(1, 1, 1, -1))
+    ref = F.conv2d(ref, k1d(9).view(1, 1, -1, 1))
+    out = _gaussian_blur(x, ksize, sigma)
+    assert out.shape == x.shape
+    assert (out - ref).abs().max() < 1e-6

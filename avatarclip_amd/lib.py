@@ -25,6 +25,8 @@ _SIGS = {
                                   P, P, P]),
     "avc_render_points_bwd": (c_int, [c_int, P, P, P, P, c_int, c_int, c_float, c_long, P, P, P, P, P, P, P, P, c_long,
                                       P]),
+    "avc_mc_classify": (c_int, [P, c_int, c_int, c_int, c_float, P, P, P, P]),
+    "avc_mc_emit": (c_int, [P, c_int, c_int, c_int, c_float, P, P, P, P, P, P, P, P, P]),
     "avc_vit_linear": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "avc_vit_attention_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "avc_vit_attention_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),

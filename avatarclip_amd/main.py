@@ -1,5 +1,5 @@
 """CLI with the reference's flags (AvatarGen/AppearanceGen/main.py:947-980):
-   python -m avatarclip_amd.main --mode {train,train_clip} --conf X [--is_continue] [--gpu N] [--case NAME]
+   python -m avatarclip_amd.main --mode {train,train_clip,validate_mesh} --conf X [--is_continue] [--gpu N] [--case NAME]
 Multi-GPU (view-sharded): torchrun --nproc-per-node N -m avatarclip_amd.main --mode train_clip --conf X"""
 import argparse
 import logging
@@ -23,8 +23,13 @@ def main():
     args = parser.parse_args()
     rank, world, local_rank = parallel.init_from_env()
     torch.cuda.set_device(local_rank if world > 1 else args.gpu)
+    if args.mode == "validate_mesh":
+        args.is_continue = True
     runner = Runner(args.conf, args.mode, args.case, args.is_continue)
-    if args.mode == "train":
+    if args.mode == "validate_mesh":
+        # main.py:972-974 (the reference then also renders turn-table videos: render_geometry_cast_light, not built)
+        runner.validate_mesh(world_space=True, resolution=512, threshold=args.mcube_threshold)
+    elif args.mode == "train":
         runner.train()
     elif args.mode == "train_clip":
         if args.clip_weights is not None:
@@ -33,7 +38,7 @@ def main():
         runner.init_smpl()
         runner.train_clip()
     else:
-        raise NotImplementedError("mode %s (mesh export / visualisation) is outside this round's hot-path scope" % args.mode)
+        raise NotImplementedError("mode %s (visualisation) is outside this round's scope" % args.mode)
 
 
 if __name__ == "__main__":

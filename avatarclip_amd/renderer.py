@@ -122,4 +122,9 @@ class NeuSRenderer:
         }
 
     def extract_geometry(self, bound_min, bound_max, resolution, threshold=0.0):
-        raise NotImplementedError("mesh extraction (renderer.py:10-36) is outside the hot-path scope of this round")
+        """renderer.py:399-404: marching cubes of -sdf at `threshold` on a resolution^3 grid -> (vertices, triangles)"""
+        from . import mesh
+        dev = next(self.sdf_network.parameters()).device
+        pk = self.engine.pack(self.flat_params())
+        return mesh.extract_geometry(bound_min, bound_max, resolution, threshold,
+                                     lambda pts: -self.engine.sdf_pts(pk, pts), dev)

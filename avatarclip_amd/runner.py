@@ -447,6 +447,47 @@ class Runner:
         return torch.cat(outs, 0).reshape(H, W, 3).clamp(0, 1)
 
 
+    def validate_mesh(self, world_space=False, resolution=256, threshold=0.0):
+        """main.py:850-919: marching cubes of -sdf over the dataset bounding box, vertex colours picked from six axis views
+        (per vertex the view whose rendered depth is closest to the true camera-vertex distance), PLY export.
+        (`world_space` is accepted and unused, as in the reference.)"""
+        from . import mesh
+        bound_min = torch.tensor(self.dataset.object_bbox_min, dtype=torch.float32)
+        bound_max = torch.tensor(self.dataset.object_bbox_max, dtype=torch.float32)
+        vertices, triangles = self.renderer.extract_geometry(bound_min, bound_max, resolution=resolution, threshold=threshold)
+        os.makedirs(os.path.join(self.base_exp_dir, "meshes"), exist_ok=True)
+        pt = torch.from_numpy(vertices).to(self.device).reshape(-1, 3).float()
+        rgb_final, diff_final = None, None
+        chunk = self.batch_size * 64      # rays per render call: no gradient is kept, only the panel-free forward runs
+        for eye in ([0, 0, 2], [0, 0, -2], [0, 2, 0], [0, -2, 0], [2, 0, 0], [-2, 0, 0]):
+            ro_all = torch.tensor(eye, dtype=torch.float32, device=self.device).reshape(1, 3).repeat(pt.shape[0], 1)
+            rd_all = pt - ro_all
+            dist = torch.norm(rd_all, dim=-1)
+            rd_all = rd_all / dist.reshape(-1, 1)
+            rgbs, diffs = [], []
+            for ro, rd, di in zip(ro_all.split(chunk), rd_all.split(chunk), dist.split(chunk)):
+                near, far = self.dataset.near_far_from_sphere(ro, rd)
+                bg = torch.ones([1, 3], device=self.device) if self.use_white_bkgd else None
+                with torch.no_grad():
+                    out = self.renderer.render(ro.contiguous(), rd.contiguous(), near, far,
+                                               cos_anneal_ratio=self.get_cos_anneal_ratio(), background_rgb=bg)
+                rgbs.append(out["extra_color_fine"] if self.extra_color else out["color_fine"])
+                depth = (out["mid_z_vals"] * out["weights"]).sum(dim=1)
+                diffs.append((depth - di).abs())
+            rgb, diff = torch.cat(rgbs, 0), torch.cat(diffs, 0)
+            if rgb_final is None:
+                rgb_final, diff_final = rgb.clone(), diff.clone()
+            else:
+                ind = diff_final > diff
+                rgb_final[ind] = rgb[ind]
+                diff_final[ind] = diff[ind]
+        colors = (255 * np.clip(rgb_final.cpu().numpy(), 0, 1)).astype(np.uint8) if rgb_final is not None else None
+        path = os.path.join(self.base_exp_dir, "meshes", "{:0>8d}.ply".format(self.iter_step))
+        mesh.write_ply(path, vertices, triangles, colors)
+        logging.info("mesh: %d vertices, %d triangles -> %s", vertices.shape[0], triangles.shape[0], path)
+        return path
+
+
 def clip_vit_random_state_dict(seed):
     """Seeded ViT-B/32 weights with OpenAI's init scales and key names (used only when no real weights are given)."""
     g = torch.Generator().manual_seed(seed)

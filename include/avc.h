@@ -95,6 +95,18 @@ int avc_weight_grad(const void* panels, int ptiles, int pa, int ta, int pb, int 
 int avc_weight_grad_all(const void* panels, int ptiles, int npairs, const int* pairs /* host */, long nblk, float* partial,
                         float* bias_partial, int nsplit, int out_stride, int bias_stride, void* stream);
 
+/* ---- mesh extraction (Runner.validate_mesh, main.py:850-919; renderer.py:10-36; mcubes.marching_cubes) ----
+ * Marching cubes over u[nx][ny][nz] (row-major, the reference's extract_fields layout) at iso level `iso`, inside = u > iso,
+ * one welded vertex per sign-changing grid edge.  Pass 1 writes, per grid point p, the flags of the three edges it owns
+ * (vflag[3p + axis]) and the triangle count of the cell whose low corner it is (ccount[p]); the caller turns both into
+ * exclusive prefix sums (vid, coff); pass 2 writes vertices (index coordinates, float32: the caller applies
+ * renderer.py:35) and triangles (vertex ids).  ntri_table[256], tri_table[256][5][3], edge_table[12][4] = (dx,dy,dz,axis):
+ * device copies of avatarclip_amd/mc_tables.py. */
+int avc_mc_classify(const float* u, int nx, int ny, int nz, float iso, const int* ntri_table, int* vflag, int* ccount,
+                    void* stream);
+int avc_mc_emit(const float* u, int nx, int ny, int nz, float iso, const int* vflag, const int* vid, const int* ccount,
+                const int* coff, const signed char* tri_table, const int* edge_table, float* verts, int* tris, void* stream);
+
 /* ---- CLIP ViT-B/32 image encoder (perceptor.encode_image, main.py:512,518,524; OpenAI clip/model.py) ----
  * y[M,N] = act(x[M,K] W^T + bias) (+ residual); W pre-packed bf16 [N/32][K/16][64][8] (lane (n,h): W[32t+n][16s+8h+j]).
  * act 1 = QuickGELU (y_pre, if given, receives the pre-activation for the backward).  The backward dX = dY W is the same

@@ -38,16 +38,28 @@ class _Lin:
         self.b = None if b is None else b.float().to(dev).contiguous()
 
 
+_workspace = {}
+
+
+def _ws(device, nbytes):
+    """bf16 fragment copy of the activations of one avc_vit_linear call (stream-ordered reuse)"""
+    key = str(device)
+    if key not in _workspace or _workspace[key].numel() < nbytes:
+        _workspace[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+    return _workspace[key]
+
+
 def _linear_raw(x2d, wp, bias, residual, N, K, act, want_pre):
     lib = L.load()
     M = x2d.shape[0]
     y = torch.empty(M, N, device=x2d.device, dtype=torch.float32)
     pre = torch.empty_like(y) if (act and want_pre) else None
+    ws = _ws(x2d.device, lib.avc_vit_workspace_bytes(min(M, 128), K))
     for m0 in range(0, M, 128):
         m1 = min(M, m0 + 128)
         off = lambda t, cols: None if t is None else t.data_ptr() + m0 * cols * 4
         L.check(lib.avc_vit_linear(off(x2d, K), L.ptr(wp), L.ptr(bias), off(residual, N), off(y, N), off(pre, N),
-                                   m1 - m0, N, K, act, L.stream()), "avc_vit_linear")
+                                   m1 - m0, N, K, act, L.ptr(ws), L.stream()), "avc_vit_linear")
     return y, pre
 
 

@@ -1,61 +1,80 @@
 // CLIP ViT-B/32 image-encoder kernels (perceptor.encode_image, main.py:512; OpenAI clip/model.py VisionTransformer).
 //   avc_vit_linear   Y[M,N] = act(X[M,K] W[N,K]^T + b) (+ residual)   -- bf16 MFMA 32x32x16, fp32 accumulate.
-//                    M = 50..100 tokens: the GEMM is weight-streaming bound, so W is pre-packed in B-operand
-//                    fragment order (one coalesced 16-B load per lane per k-step), the K range is split over the
-//                    4 wavefronts of a workgroup and reduced through LDS, one workgroup per 32 output columns.
+//                    M = 50..100 tokens: the GEMM is weight-streaming / latency bound, so W is pre-packed in B-operand
+//                    fragment order and X is packed into A-operand fragments by a pre-pass (one coalesced 16-B load per
+//                    lane per k-step for both), the K range is dealt to the 8 wavefronts of a workgroup and reduced
+//                    through LDS, one workgroup per 32 output columns.
 //                    The same kernel computes dX = dY W with the pre-packed W^T (weights are frozen: no dW).
 //   avc_vit_attention_fwd / _bwd   12-head attention over 50 tokens, one workgroup per (image, head), fp32 in LDS.
 #include "avc_common.h"
 #include "../../include/avc.h"
 
 #define VIT_MAX_MT 4   // up to 128 rows (tokens) per launch
+#define VIT_WAVES 8    // wavefronts per workgroup = K-split factor
 
+// X[M,K] fp32 -> bf16 A-operand fragments [m-tile][k-step][lane][8] (lane (i,h) holds X[32m+i][16s+8h+j]): the GEMM then
+// reads its activations with the same coalesced 16-B-per-lane loads as its weights.
+__global__ __launch_bounds__(64) void vit_pack_x_kernel(const float* __restrict__ X, b8* __restrict__ xs, int M, int K) {
+  const int s = blockIdx.x, m = blockIdx.y, KS = K >> 4;
+  const int lane = threadIdx.x, n = lane & 31, h = lane >> 5;
+  const int row = 32 * m + n;
+  b8 xf;
+  if (row < M) {
+    const f4* xp = reinterpret_cast<const f4*>(X + (long)row * K + 16 * s + 8 * h);
+    const f4 a = xp[0], b = xp[1];
+    xf[0] = (__bf16)a[0]; xf[1] = (__bf16)a[1]; xf[2] = (__bf16)a[2]; xf[3] = (__bf16)a[3];
+    xf[4] = (__bf16)b[0]; xf[5] = (__bf16)b[1]; xf[6] = (__bf16)b[2]; xf[7] = (__bf16)b[3];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xf[j] = (__bf16)0.f;
+  }
+  xs[((long)m * KS + s) * 64 + lane] = xf;
+}
+
+// One workgroup per 32 output columns; the K range is dealt round-robin to 8 wavefronts (k-step s goes to wave s % 8), each
+// wave keeps 6 k-steps of loads in flight (the GEMM is a latency chain otherwise: M <= 128 rows give the matrix core nothing
+// to hide a round trip behind), partial sums are reduced through LDS in a fixed tree (deterministic).
 template <int MT>
-__global__ __launch_bounds__(256) void vit_linear_kernel(const float* __restrict__ X, const b8* __restrict__ Wp,
-                                                         const float* __restrict__ bias, const float* __restrict__ res,
-                                                         float* __restrict__ Y, float* __restrict__ Ypre, int M, int N, int K,
-                                                         int act) {
-  __shared__ float red[3][MT][64][16];
+__global__ __launch_bounds__(64 * VIT_WAVES) void vit_linear_kernel(const b8* __restrict__ Xs, const b8* __restrict__ Wp,
+                                                                    const float* __restrict__ bias, const float* __restrict__ res,
+                                                                    float* __restrict__ Y, float* __restrict__ Ypre, int M, int N,
+                                                                    int K, int act) {
+  __shared__ float red[VIT_WAVES / 2][MT][64][16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int n = lane & 31, h = lane >> 5;
   const int t = blockIdx.x;           // output column tile
   const int KS = K >> 4;              // k-steps of 16
-  const int ks_per = (KS + 3) >> 2;
-  const int s0 = wv * ks_per, s1 = min(KS, s0 + ks_per);
   facc acc[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
   const b8* wp = Wp + ((long)t * KS) * 64 + lane;
-  // 4 k-steps per trip: the loop is a chain of dependent L2/HBM round trips (12..48 trips per wave at ~1.5 us each was the
-  // whole 46 us of a call); unrolled, the loads of four k-steps are in flight together
-#pragma unroll 4
-  for (int s = s0; s < s1; ++s) {
+  const b8* xp = Xs + lane;
+#pragma unroll 6
+  for (int s = wv; s < KS; s += VIT_WAVES) {
     const b8 w = wp[(long)s * 64];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int row = 32 * m + n;   // as A operand: lane (i = token, h) holds X[token][16 s + 8 h + j]
-      b8 xf;
-      if (row < M) {
-        const f4* xp = reinterpret_cast<const f4*>(X + (long)row * K + 16 * s + 8 * h);
-        const f4 a = xp[0], b = xp[1];
-        xf[0] = (__bf16)a[0]; xf[1] = (__bf16)a[1]; xf[2] = (__bf16)a[2]; xf[3] = (__bf16)a[3];
-        xf[4] = (__bf16)b[0]; xf[5] = (__bf16)b[1]; xf[6] = (__bf16)b[2]; xf[7] = (__bf16)b[3];
-      } else {
+    for (int m = 0; m < MT; ++m) acc[m] = MF<b8>::mma(xp[((long)m * KS + s) * 64], w, acc[m]);
+  }
+  // tree reduction 8 -> 4 -> 2 -> 1
 #pragma unroll
-        for (int j = 0; j < 8; ++j) xf[j] = (__bf16)0.f;
-      }
-      acc[m] = MF<b8>::mma(xf, w, acc[m]);
+  for (int half = VIT_WAVES / 2; half >= 1; half >>= 1) {
+    if (wv >= half && wv < 2 * half) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wv - half][m][lane][r] = acc[m][r];
     }
-  }
-  if (wv > 0) {
+    __syncthreads();
+    if (wv < half) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) red[wv - 1][m][lane][r] = acc[m][r];
+        for (int r = 0; r < 16; ++r) acc[m][r] += red[wv][m][lane][r];
+    }
+    __syncthreads();
   }
-  __syncthreads();
   if (wv == 0) {
     const int col = 32 * t + n;
     const float bv = bias ? bias[col] : 0.f;
@@ -65,7 +84,7 @@ __global__ __launch_bounds__(256) void vit_linear_kernel(const float* __restrict
       for (int r = 0; r < 16; ++r) {
         const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row < M) {
-          float v = acc[m][r] + red[0][m][lane][r] + red[1][m][lane][r] + red[2][m][lane][r] + bv;
+          float v = acc[m][r] + bv;
           const long o = (long)row * N + col;
           if (act == 1) {
             if (Ypre) Ypre[o] = v;
@@ -79,22 +98,30 @@ __global__ __launch_bounds__(256) void vit_linear_kernel(const float* __restrict
   }
 }
 
+extern "C" long avc_vit_workspace_bytes(int M, int K) {
+  const long mt = (M + 31) / 32;
+  return mt * (K / 16) * 1024L;
+}
+
 extern "C" int avc_vit_linear(const float* x, const void* w_packed, const float* bias, const float* residual, float* y,
-                              float* y_pre, int M, int N, int K, int act, void* stream) {
+                              float* y_pre, int M, int N, int K, int act, void* workspace, void* stream) {
   if (M <= 0) return 0;
   if ((N & 31) || (K & 15) || M > 32 * VIT_MAX_MT) {
     avc_set_error("avc_vit_linear: need N % 32 == 0, K % 16 == 0, M <= 128");
     return 1;
   }
+  if (!workspace) { avc_set_error("avc_vit_linear: workspace == NULL (avc_vit_workspace_bytes)"); return 1; }
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid(N / 32), block(256);
-  const b8* wp = (const b8*)w_packed;
   const int mt = (M + 31) / 32;
+  b8* xs = (b8*)workspace;
+  hipLaunchKernelGGL(vit_pack_x_kernel, dim3(K / 16, mt), dim3(64), 0, s, x, xs, M, K);
+  const dim3 grid(N / 32), block(64 * VIT_WAVES);
+  const b8* wp = (const b8*)w_packed;
   switch (mt) {
-    case 1: hipLaunchKernelGGL((vit_linear_kernel<1>), grid, block, 0, s, x, wp, bias, residual, y, y_pre, M, N, K, act); break;
-    case 2: hipLaunchKernelGGL((vit_linear_kernel<2>), grid, block, 0, s, x, wp, bias, residual, y, y_pre, M, N, K, act); break;
-    case 3: hipLaunchKernelGGL((vit_linear_kernel<3>), grid, block, 0, s, x, wp, bias, residual, y, y_pre, M, N, K, act); break;
-    default: hipLaunchKernelGGL((vit_linear_kernel<4>), grid, block, 0, s, x, wp, bias, residual, y, y_pre, M, N, K, act); break;
+    case 1: hipLaunchKernelGGL((vit_linear_kernel<1>), grid, block, 0, s, xs, wp, bias, residual, y, y_pre, M, N, K, act); break;
+    case 2: hipLaunchKernelGGL((vit_linear_kernel<2>), grid, block, 0, s, xs, wp, bias, residual, y, y_pre, M, N, K, act); break;
+    case 3: hipLaunchKernelGGL((vit_linear_kernel<3>), grid, block, 0, s, xs, wp, bias, residual, y, y_pre, M, N, K, act); break;
+    default: hipLaunchKernelGGL((vit_linear_kernel<4>), grid, block, 0, s, xs, wp, bias, residual, y, y_pre, M, N, K, act); break;
   }
   return avc_check_launch("avc_vit_linear");
 }

@@ -112,7 +112,10 @@ int avc_mc_emit(const float* u, int nx, int ny, int nz, float iso, const int* vf
  * act 1 = QuickGELU (y_pre, if given, receives the pre-activation for the backward).  The backward dX = dY W is the same
  * call with the packed W^T (weights are frozen in AvatarCLIP: main.py:260). M <= 128. */
 int avc_vit_linear(const float* x, const void* w_packed, const float* bias, const float* residual, float* y,
-                   float* y_pre, int M, int N, int K, int act, void* stream);
+                   float* y_pre, int M, int N, int K, int act, void* workspace /* avc_vit_workspace_bytes(M, K) */,
+                   void* stream);
+/* bytes of the bf16 fragment copy of x that avc_vit_linear builds in `workspace` */
+long avc_vit_workspace_bytes(int M, int K);
 /* multi-head self-attention of ResidualAttentionBlock over T=50 tokens, head dim 64: qkv[B,T,3W] -> out[B,T,W] */
 int avc_vit_attention_fwd(const float* qkv, float* out, int B, int T, int width, int heads, void* stream);
 int avc_vit_attention_bwd(const float* qkv, const float* dout, float* dqkv, int B, int T, int width, int heads,

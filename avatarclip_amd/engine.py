@@ -94,6 +94,7 @@ class Engine:
         self._partials = None
         self._bpartials = None
         self._pairs_host = np.ascontiguousarray(np.asarray(self.dl.lay.pairs, dtype=np.int32).reshape(-1, 6))
+        self._sdf_bias0 = int(self.dl.lay.pbase["sdf.b%d" % (spec.NMID + 2)])   # flat index of bias[0] of the last SDF layer
         self._packed_key = None
         self._packed = None
 
@@ -255,6 +256,9 @@ class Engine:
         grad.index_add_(0, self.dl.un_tgt, gout[self.dl.un_src] * self.dl.un_scale)
         if lay.gbias_size:
             grad.index_add_(0, self.dl.ub_tgt, gbias[self.dl.ub_src])
+        # d loss / d (sdf bias) = sum of d_sdf over all points: a sum with heavy cancellation (the eikonal term pulls both
+        # ways), which the bf16 panel of d_sdf gets wrong by several percent -- take it from the fp32 tensor instead
+        grad[self._sdf_bias0] = d_sdf.sum()
         return grad
 
 

@@ -115,3 +115,58 @@ def test_train_clip_iteration_matches_oracle_driven_iteration():
                   "without it", ((d.double().norm() ** 2 - d[k].double() ** 2).sqrt() / gb.double().norm()).item())
         assert rel < 5e-2 and cos > 0.995, (n, rel, cos)
     print("worst per-tensor relative gradient error", worst)
+
+
+@gpu
+def test_runner_train_neus_init_and_checkpoint_round_trip(tmp_path):
+    """Runner.train (main.py:180-256, BASELINE config 1) on a synthetic 4-image dataset in the reference's on-disk format
+    (transforms_train.json + PNGs): the loss falls, the checkpoint has the reference's keys (main.py:622-629) and resumes."""
+    import json
+    from PIL import Image
+    import bench
+    from oracle import neus_oracle as O
+    from avatarclip_amd.runner import Runner
+    res = 32
+    data = tmp_path / "data"
+    (data / "img").mkdir(parents=True)
+    frames = []
+    yy, xx = np.mgrid[0:res, 0:res]
+    for k in range(4):
+        ang = 2 * np.pi * k / 4
+        eye = np.array([1.5 * np.sin(ang), 0.2, 1.5 * np.cos(ang)])
+        pose = O.lookat(eye, np.zeros(3), np.array([0., 1, 0]))
+        disk = ((xx - res / 2 + 0.5) ** 2 + (yy - res / 2 + 0.5) ** 2) < (0.3 * res) ** 2     # a sphere seen from anywhere
+        img = np.zeros((res, res, 3), np.uint8)
+        img[disk] = (200, 150 + 20 * k, 100)
+        Image.fromarray(img).save(str(data / "img" / ("%04d.png" % k)))
+        frames.append({"file_path": "img/%04d" % k, "transform_matrix": np.asarray(pose).tolist()})
+    with open(data / "transforms_train.json", "w") as fp:
+        json.dump({"camera_angle_x": float(np.pi / 3), "frames": frames}, fp)
+    conf = bench.make_conf(res, 32, small=True)
+    conf.put("general.base_exp_dir", str(tmp_path / "exp"))
+    conf.put("dataset.data_dir", str(data))
+    conf.put("train.end_iter", 30)
+    conf.put("train.batch_size", 256)
+    conf.put("train.warm_up_end", 0)
+    conf.put("train.save_freq", 30)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    dev = torch.device("cuda")
+    runner = Runner(None, mode="train", conf=conf, device=dev)
+    assert runner.dataset.n_images == 4
+    first = runner.train_iteration(runner.dataset.gen_random_rays_at(0, 256)).item()
+    runner.train()
+    last = runner.train_iteration(runner.dataset.gen_random_rays_at(0, 256)).item()
+    print("NeuS-init loss", first, "->", last)
+    assert np.isfinite(first) and np.isfinite(last) and last < first
+    ck = tmp_path / "exp" / "checkpoints" / "ckpt_000030.pth"
+    assert ck.exists()
+    blob = torch.load(str(ck), map_location="cpu", weights_only=False)
+    assert set(blob.keys()) == {"sdf_network_fine", "variance_network_fine", "color_network_fine", "optimizer", "iter_step"}
+    assert any(k.endswith("weight_g") for k in blob["sdf_network_fine"]) and "variance" in blob["variance_network_fine"]
+    r2 = Runner(None, mode="train", conf=conf, device=dev)
+    r2.load_checkpoint("ckpt_000030.pth")
+    assert r2.iter_step == 30
+    sd_now = {k: v.clone() for k, v in blob["sdf_network_fine"].items()}
+    for k, v in r2.sdf_network.state_dict().items():
+        assert torch.equal(v.cpu(), sd_now[k].cpu())

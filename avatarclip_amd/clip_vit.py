@@ -136,6 +136,9 @@ class ClipVisionB32:
                 fc=_Lin(sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"], dev),
                 proj=_Lin(sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"], dev)))
         self.proj = _Lin(sd["visual.proj"].t().contiguous(), None, dev)
+        # the text tower is built on demand from the same state dict (clip_text.ClipTextB32) when it carries one
+        self._text_sd = state_dict if "token_embedding.weight" in state_dict else None
+        self._text = None
 
     def eval(self):
         return self
@@ -165,8 +168,15 @@ class ClipVisionB32:
         return LinearFn.apply(x, self.proj, 0, None)
 
     def encode_text(self, tokens):
-        raise NotImplementedError("the text tower runs once per prompt at start-up (main.py:273-288) and is outside the "
-                                  "hot path; supply the cached 512-d prompt embedding instead (SURVEY.md §8 row f-3)")
+        """main.py:276,282,288 (start-up only): needs a state dict that carries the text tower (a full OpenAI ViT-B/32
+        checkpoint does; the seeded vision-only weights of the benchmark do not)"""
+        if self._text is None:
+            if self._text_sd is None:
+                raise RuntimeError("this perceptor was built from vision-only weights: no text tower to encode prompts with "
+                                   "(supply a full CLIP state dict, or cached prompt embeddings to Runner.init_clip)")
+            from .clip_text import ClipTextB32
+            self._text = ClipTextB32(self._text_sd, self.device)
+        return self._text.encode_text(tokens)
 
 
 def clip_preprocess(img_hw3: torch.Tensor) -> torch.Tensor:

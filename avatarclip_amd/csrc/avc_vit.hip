@@ -177,6 +177,46 @@ __global__ __launch_bounds__(64) void vit_attn_fwd_kernel(const float* __restric
   for (int c = 0; c < AT_D; ++c) op[c] = o[c];
 }
 
+// Text tower (clip/model.py encode_text: 77 tokens, 8 heads of 64, causal mask): forward only -- prompts are encoded once per
+// run (main.py:273-288).  One workgroup per (sequence, head), thread i = query row i, K/V rows in LDS, online softmax.
+#define TA_TMAX 128
+__global__ __launch_bounds__(TA_TMAX) void text_attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T,
+                                                                int Wd, int heads, float scale, int causal) {
+  extern __shared__ __attribute__((aligned(16))) float tsm[];
+  float (*Ks)[AT_LD] = reinterpret_cast<float (*)[AT_LD]>(tsm);
+  float (*Vs)[AT_LD] = Ks + T;
+  const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
+  const int i = threadIdx.x;
+  const float* base = qkv + (long)b * T * 3 * Wd + hd * AT_D;
+  for (int e = threadIdx.x; e < T * AT_D; e += TA_TMAX) {
+    const int r = e / AT_D, c = e % AT_D;
+    Ks[r][c] = base[(long)r * 3 * Wd + Wd + c];
+    Vs[r][c] = base[(long)r * 3 * Wd + 2 * Wd + c];
+  }
+  __syncthreads();
+  if (i >= T) return;
+  float q[AT_D], o[AT_D];
+#pragma unroll
+  for (int c = 0; c < AT_D; ++c) { q[c] = base[(long)i * 3 * Wd + c] * scale; o[c] = 0.f; }
+  float mx = -1e30f, sum = 0.f;
+  const int jend = causal ? i + 1 : T;
+  for (int j = 0; j < jend; ++j) {
+    float sc = 0.f;
+#pragma unroll
+    for (int c = 0; c < AT_D; ++c) sc += q[c] * Ks[j][c];
+    const float mn = fmaxf(mx, sc);
+    const float corr = __expf(mx - mn), pj = __expf(sc - mn);
+    sum = sum * corr + pj;
+#pragma unroll
+    for (int c = 0; c < AT_D; ++c) o[c] = o[c] * corr + pj * Vs[j][c];
+    mx = mn;
+  }
+  const float inv = 1.f / sum;
+  float* op = out + ((long)b * T + i) * Wd + hd * AT_D;
+#pragma unroll
+  for (int c = 0; c < AT_D; ++c) op[c] = o[c] * inv;
+}
+
 __global__ __launch_bounds__(64) void vit_attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                           float* __restrict__ dqkv, int Wd, int heads, float scale) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -257,6 +297,19 @@ extern "C" int avc_vit_attention_fwd(const float* qkv, float* out, int B, int T,
   if (T != AT_T || width != heads * AT_D) { avc_set_error("avc_vit_attention: built for 50 tokens, head dim 64"); return 1; }
   hipLaunchKernelGGL(vit_attn_fwd_kernel, dim3(B * heads), dim3(64), 0, (hipStream_t)stream, qkv, out, width, heads, 0.125f);
   return avc_check_launch("avc_vit_attention_fwd");
+}
+extern "C" int avc_text_attention_fwd(const float* qkv, float* out, int B, int T, int width, int heads, int causal, void* stream) {
+  if (T < 1 || T > TA_TMAX || width != heads * AT_D) { avc_set_error("avc_text_attention_fwd: 1 <= T <= 128, head dim 64"); return 1; }
+  if (B <= 0) return 0;
+  const size_t lds = 2 * (size_t)T * AT_LD * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)text_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TA_TMAX * AT_LD * 4);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(text_attn_fwd_kernel, dim3(B * heads), dim3(TA_TMAX), lds, (hipStream_t)stream, qkv, out, T, width, heads,
+                     0.125f, causal);
+  return avc_check_launch("avc_text_attention_fwd");
 }
 extern "C" int avc_vit_attention_bwd(const float* qkv, const float* dout, float* dqkv, int B, int T, int width, int heads,
                                      void* stream) {

@@ -205,10 +205,25 @@ class Runner:
         self.clip_preprocess = clip_vit.clip_preprocess
         te = text_embeddings or {}
 
+        tokenizer = None
+        if getattr(perceptor, "_text_sd", None) is not None:
+            try:
+                from .tokenizer import SimpleTokenizer
+                tokenizer = SimpleTokenizer(self.conf.get_string("clip.bpe_path", default=None))
+            except FileNotFoundError as e:
+                logging.warning("%s", e)
+
         def emb(key, seed):
             if key in te:
                 return te[key].to(self.device).float().reshape(1, -1)
-            logging.warning("no text embedding for clip.%s: using a seeded random unit vector (text tower is not on the hot path)", key)
+            text = self.conf.get_string("clip." + key, default=None)
+            if tokenizer is not None and text is not None:
+                # main.py:272-288: clip.tokenize + perceptor.encode_text, detached
+                from .tokenizer import tokenize
+                print("%s: %s" % (key, text))
+                return self.perceptor.encode_text(tokenize([text], tokenizer)).detach()
+            logging.warning("no text embedding for clip.%s (needs full CLIP weights + the BPE table, or text_embeddings=): "
+                            "using a seeded random unit vector", key)
             g = torch.Generator().manual_seed(seed)
             v = torch.randn(1, 512, generator=g)
             return (v / v.norm()).to(self.device)

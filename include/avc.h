@@ -118,6 +118,9 @@ int avc_vit_linear(const float* x, const void* w_packed, const float* bias, cons
 long avc_vit_workspace_bytes(int M, int K);
 /* multi-head self-attention of ResidualAttentionBlock over T=50 tokens, head dim 64: qkv[B,T,3W] -> out[B,T,W] */
 int avc_vit_attention_fwd(const float* qkv, float* out, int B, int T, int width, int heads, void* stream);
+/* text tower (perceptor.encode_text, main.py:276-288; clip/model.py): self-attention over T <= 128 tokens, head dim 64, with
+ * the causal mask of CLIP's text transformer when `causal` != 0.  Forward only (prompts are encoded once, detached). */
+int avc_text_attention_fwd(const float* qkv, float* out, int B, int T, int width, int heads, int causal, void* stream);
 int avc_vit_attention_bwd(const float* qkv, const float* dout, float* dqkv, int B, int T, int width, int heads,
                           void* stream);
 

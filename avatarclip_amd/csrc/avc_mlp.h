@@ -130,6 +130,70 @@ __device__ __forceinline__ void layer_s(ST& st, const V* __restrict__ blob, int 
   epi(NT - 1, prev);
   __builtin_amdgcn_sched_barrier(0);
 }
+// ---- the same layer with the epilogue's global loads issued BEFORE the MFMA chain they trail: pre(t) returns the raw loads
+// ---- (panel tiles read back by the backward sweeps), epi(t, acc, data) consumes them after the chain of tile t+1.  The
+// ---- backward kernel keeps only ~16 KiB of reads in flight per CU when every epilogue loads and immediately waits; one
+// ---- chain (~600 cycles) of head start costs no extra live set beyond the loaded registers themselves.
+#ifndef AVC_DEEP_PF1
+#define AVC_DEEP_PF1 0
+#endif
+#define AVC_PRE(...) [&](int t) __attribute__((always_inline)) { __VA_ARGS__ }
+#define AVC_EPID(DT, ...) [&](int t, const facc& acc, const DT& d) __attribute__((always_inline)) { __VA_ARGS__ }
+// DEEP = false: pre(t-1) goes out before the chain of tile t (one chain of head start, one load set live);
+// DEEP = true:  pre(t) goes out before the chain of tile t (two chains + one epilogue of head start, two sets live) --
+//               measured slower for the three-array loads of the reverse sweep (register pressure), see DESIGN.md 5.
+template <bool AVC_PRE_DEEP, typename V, int KS, int NT, class ST, typename Pre, typename Epi>
+__device__ __forceinline__ void layer_sq_(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&in)[KS],
+                                         Pre&& pre, Epi&& epi) {
+  constexpr int G = ST::template group<KS>();
+  constexpr int NG = (NT + G - 1) / G;
+  facc prev;
+  decltype(pre(0)) dprev{}, dcur{};
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    AVC_SYNC();
+    if (g + 1 < NG) {
+      Next n;
+      n.ptr = blob + (offw >> 3) + (long)((g + 1) * G * KS) * 64;
+      n.chunks = KS * ((NT - (g + 1) * G) < G ? (NT - (g + 1) * G) : G);
+      stage_issue(st, n, st.par ^ 1);
+    } else {
+      stage_issue(st, after, st.par ^ 1);
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const int t = g * G + j;
+      if (t < NT) {
+        if (AVC_PRE_DEEP) {
+          dcur = pre(t);
+          __builtin_amdgcn_sched_barrier(0);   // the loads go out before the chain
+        } else if (t > 0) {
+          dprev = pre(t - 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        facc acc = tile_mma<V, KS>(st, j, in);
+        if (t > 0) { epi(t - 1, prev, dprev); interleave_mfma_valu<KS>(); }
+        prev = acc;
+        if (AVC_PRE_DEEP) dprev = dcur;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    st.par ^= 1;
+  }
+  if (!AVC_PRE_DEEP) dprev = pre(NT - 1);
+  epi(NT - 1, prev, dprev);
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <typename V, int KS, int NT, class ST, typename Pre, typename Epi>
+__device__ __forceinline__ void layer_sq(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&in)[KS],
+                                         Pre&& pre, Epi&& epi) {
+  layer_sq_<false, V, KS, NT>(st, blob, offw, after, in, pre, epi);
+}
+template <typename V, int KS, int NT, class ST, typename Pre, typename Epi>
+__device__ __forceinline__ void layer_sqd(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&in)[KS],
+                                          Pre&& pre, Epi&& epi) {
+  layer_sq_<AVC_DEEP_PF1 != 0, V, KS, NT>(st, blob, offw, after, in, pre, epi);
+}
 template <typename V, int KA, int KB, int NT, class ST, typename Epi>
 __device__ __forceinline__ void layer2_s(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&ina)[KA],
                                          const V (&inb)[KB], Epi&& epi) {

@@ -149,6 +149,35 @@ __device__ __forceinline__ float second_term(float gbar_h, float g_a, float s) {
   const float r = s > 1e-30f ? __builtin_amdgcn_rcpf(s) : 0.f;
   return gbar_h * g_a * (AVC_BETA * (1.f - s) * r);
 }
+// split form for layer_sq: the raw loads ...
+struct PF1 { b8 a0, a1; };
+struct PF3 { b8 a0, a1, b0, b1, c0, c1; };
+__device__ __forceinline__ PF1 pfetch1(const b8* __restrict__ panel_blk, int tile, int lane) {
+  const b8* src = panel_blk + (long)tile * 128 + lane;
+  PF1 d;
+  d.a0 = src[0];
+  d.a1 = src[64];
+  return d;
+}
+__device__ __forceinline__ PF3 pfetch3(const b8* __restrict__ panel_blk, int ta, int tb, int tc, int lane) {
+  const b8* sa = panel_blk + (long)ta * 128 + lane;
+  const b8* sb = panel_blk + (long)tb * 128 + lane;
+  const b8* sc = panel_blk + (long)tc * 128 + lane;
+  PF3 d;
+  d.a0 = sa[0]; d.a1 = sa[64];
+  d.b0 = sb[0]; d.b1 = sb[64];
+  d.c0 = sc[0]; d.c1 = sc[64];
+  return d;
+}
+// ... and the un-transposition at the point of use
+__device__ __forceinline__ facc ptrans(const b8& k0, const b8& k1, const b8& e0, const b8& e1) {
+  facc acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  acc = MF<b8>::mma(k0, e0, acc);
+  acc = MF<b8>::mma(k1, e1, acc);
+  return acc;
+}
 template <typename V>
 __device__ __forceinline__ void punpack_frags(const b8* __restrict__ panel_blk, int tile, int lane, const b8& e0, const b8& e1,
                                               V& f0, V& f1) {
@@ -247,7 +276,8 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
     {
       // g_h(prev) = W^T g_a ; g_a(prev) = g_h * sigma(h_prev)
 #define AVC_NSTEP(OUT, PH, PT)                                                                            \
-  AVC_EPI(const facc hv = punpack(pblk, (PH) + t, lane, e0b, e1b);                                          \
+  AVC_PRE(return pfetch1(pblk, (PH) + t, lane);),                                                           \
+  AVC_EPID(PF1, const facc hv = ptrans(d.a0, d.a1, e0b, e1b);                                               \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                   \
             OUT[2 * t][j] = (_Float16)(acc[j] * sig_from_h(hv[j]));                                         \
             OUT[2 * t + 1][j] = (_Float16)(acc[8 + j] * sig_from_h(hv[8 + j])); }                           \
@@ -256,16 +286,16 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
       h8 g[N::HK];
       h8 g2[N::HK];
       if constexpr (N::NMID == 2) {
-        layer_s<h8, N::SK, N::HT>(sg, Wf, o.v[OFF_WST], nxt<N, OFF_WM1T>(sg, Wf, o), g_s,
+        layer_sqd<h8, N::SK, N::HT>(sg, Wf, o.v[OFF_WST], nxt<N, OFF_WM1T>(sg, Wf, o), g_s,
                                          AVC_NSTEP(g, L::P_HM + N::HT, L::P_GAM + N::HT));
-        layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1T], nxt<N, OFF_WM0T>(sg, Wf, o), g,
+        layer_sqd<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1T], nxt<N, OFF_WM0T>(sg, Wf, o), g,
                                          AVC_NSTEP(g2, L::P_HM, L::P_GAM));
-        layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0T], nxt<N, OFF_W0T>(sg, Wf, o), g2,
+        layer_sqd<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0T], nxt<N, OFF_W0T>(sg, Wf, o), g2,
                                          AVC_NSTEP(g, L::P_H1, L::P_GA1));
       } else {
-        layer_s<h8, N::SK, N::HT>(sg, Wf, o.v[OFF_WST], nxt<N, OFF_WM0T>(sg, Wf, o), g_s,
+        layer_sqd<h8, N::SK, N::HT>(sg, Wf, o.v[OFF_WST], nxt<N, OFF_WM0T>(sg, Wf, o), g_s,
                                          AVC_NSTEP(g2, L::P_HM, L::P_GAM));
-        layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0T], nxt<N, OFF_W0T>(sg, Wf, o), g2,
+        layer_sqd<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0T], nxt<N, OFF_W0T>(sg, Wf, o), g2,
                                          AVC_NSTEP(g, L::P_H1, L::P_GA1));
       }
       float part[3] = {0.f, 0.f, 0.f};
@@ -424,29 +454,30 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
       pstore<b8>(pblk, live, L::P_GB0 + 1, lane, gb0[2], zero_frag<b8>(), e0b, e1b);
       // gbar_a = W gbar_h(in); gbar_h(out) = gbar_a * sigma(h_out)
 #define AVC_SECOND(OUT, PH, PT)                                                                             \
-  AVC_EPI(const facc hv = punpack(pblk, (PH) + t, lane, e0b, e1b);                                           \
+  AVC_PRE(return pfetch1(pblk, (PH) + t, lane);),                                                            \
+  AVC_EPID(PF1, const facc hv = ptrans(d.a0, d.a1, e0b, e1b);                                                \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                    \
             OUT[2 * t][j] = (__bf16)(acc[j] * sig_from_h(hv[j]));                                            \
             OUT[2 * t + 1][j] = (__bf16)(acc[8 + j] * sig_from_h(hv[8 + j])); }                              \
           pin2(OUT[2 * t], OUT[2 * t + 1]);                                                                  \
           pstore<b8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0b, e1b);)
       b8 gb1[N::HK];
-      layer_s<b8, 3, N::HT>(sg, Wb, o.v[OFF_W0G], nxt<N, OFF_WM0>(sg, Wb, o), gb0,
+      layer_sqd<b8, 3, N::HT>(sg, Wb, o.v[OFF_W0G], nxt<N, OFF_WM0>(sg, Wb, o), gb0,
                                    AVC_SECOND(gb1, L::P_H1, L::P_GBH1));
       b8 gbm[N::HK];
       b8 gbs[N::SK];
       if constexpr (N::NMID == 2) {
-        layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wb, o), gb1,
+        layer_sqd<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wb, o), gb1,
                                          AVC_SECOND(gbm, L::P_HM, L::P_GBHM));
         b8 gbm1[N::HK];
-        layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wb, o), gbm,
+        layer_sqd<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wb, o), gbm,
                                          AVC_SECOND(gbm1, L::P_HM + N::HT, L::P_GBHM + N::HT));
-        layer_s<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WS], nxt<N, OFF_WLT>(sg, Wb, o), gbm1,
+        layer_sqd<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WS], nxt<N, OFF_WLT>(sg, Wb, o), gbm1,
                                          AVC_SECOND(gbs, L::P_HS, L::P_GBHS));
       } else {
-        layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wb, o), gb1,
+        layer_sqd<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wb, o), gb1,
                                          AVC_SECOND(gbm, L::P_HM, L::P_GBHM));
-        layer_s<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WS], nxt<N, OFF_WLT>(sg, Wb, o), gbm,
+        layer_sqd<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WS], nxt<N, OFF_WLT>(sg, Wb, o), gbm,
                                          AVC_SECOND(gbs, L::P_HS, L::P_GBHS));
       }
     }
@@ -457,12 +488,13 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
 #pragma unroll
       for (int t = 0; t < N::HT; ++t) punpack_frags<b8>(pblk, L::P_DFEAT + t, lane, e0b, e1b, dfeat[2 * t], dfeat[2 * t + 1]);
       // ubar[:SKIP]/sqrt2 = (W_last[1:,:]^T dfeat + W_last[0,:] d_sdf)/sqrt2 ; 1/sqrt2 is folded into both packs
-      layer_s<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WLT], nxt<N, OFF_WST>(sg, Wb, o), dfeat, AVC_EPI(
+      layer_sq<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WLT], nxt<N, OFF_WST>(sg, Wb, o), dfeat,
+        AVC_PRE(return pfetch3(pblk, L::P_HS + t, L::P_GBHS + t, L::P_GAS + t, lane);), AVC_EPID(PF3,
         float wa[16];
         load16(T + o.v[OFF_WL0_ACC], t, h, wa);
-        const facc hv = punpack(pblk, L::P_HS + t, lane, e0b, e1b);
-        const facc bv = punpack(pblk, L::P_GBHS + t, lane, e0b, e1b);
-        const facc gv = punpack(pblk, L::P_GAS + t, lane, e0b, e1b);
+        const facc hv = ptrans(d.a0, d.a1, e0b, e1b);
+        const facc bv = ptrans(d.b0, d.b1, e0b, e1b);
+        const facc gv = ptrans(d.c0, d.c1, e0b, e1b);
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {
           const float s0 = sig_from_h(hv[j]), s1 = sig_from_h(hv[8 + j]);
           as_[2 * t][j] = (__bf16)(second_term(bv[j], gv[j], s0) + (acc[j] + wa[j] * dsdfS) * s0);
@@ -473,9 +505,10 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
       ));
       // hbar(prev) = W^T abar(cur); abar(prev) = abar'(prev) + hbar * sigma(h_prev)
 #define AVC_REVERSE(OUT, PH, PB, PG, PT)                                                                    \
-  AVC_EPI(const facc hv = punpack(pblk, (PH) + t, lane, e0b, e1b);                                           \
-          const facc bv = punpack(pblk, (PB) + t, lane, e0b, e1b);                                           \
-          const facc gv = punpack(pblk, (PG) + t, lane, e0b, e1b);                                           \
+  AVC_PRE(return pfetch3(pblk, (PH) + t, (PB) + t, (PG) + t, lane);),                                        \
+  AVC_EPID(PF3, const facc hv = ptrans(d.a0, d.a1, e0b, e1b);                                                \
+          const facc bv = ptrans(d.b0, d.b1, e0b, e1b);                                                      \
+          const facc gv = ptrans(d.c0, d.c1, e0b, e1b);                                                      \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                    \
             const float s0 = sig_from_h(hv[j]), s1 = sig_from_h(hv[8 + j]);                                  \
             OUT[2 * t][j] = (__bf16)(second_term(bv[j], gv[j], s0) + acc[j] * s0);                           \
@@ -486,15 +519,15 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
       b8 am0[N::HK];
       const Next first = nxt<N, OFF_W0>(sg, Wf0, o);   // prefetch the first tile of the next block iteration
       if constexpr (N::NMID == 2) {
-        layer_s<b8, N::SK, N::HT>(sg, Wb, o.v[OFF_WST], nxt<N, OFF_WM1T>(sg, Wb, o), as_,
+        layer_sq<b8, N::SK, N::HT>(sg, Wb, o.v[OFF_WST], nxt<N, OFF_WM1T>(sg, Wb, o), as_,
                                          AVC_REVERSE(am, L::P_HM + N::HT, L::P_GBHM + N::HT, L::P_GAM + N::HT, L::P_ABM + N::HT));
-        layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM1T], nxt<N, OFF_WM0T>(sg, Wb, o), am,
+        layer_sq<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM1T], nxt<N, OFF_WM0T>(sg, Wb, o), am,
                                          AVC_REVERSE(am0, L::P_HM, L::P_GBHM, L::P_GAM, L::P_ABM));
-        layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0T], first, am0, AVC_REVERSE(am, L::P_H1, L::P_GBH1, L::P_GA1, L::P_AB1));
+        layer_sq<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0T], first, am0, AVC_REVERSE(am, L::P_H1, L::P_GBH1, L::P_GA1, L::P_AB1));
       } else {
-        layer_s<b8, N::SK, N::HT>(sg, Wb, o.v[OFF_WST], nxt<N, OFF_WM0T>(sg, Wb, o), as_,
+        layer_sq<b8, N::SK, N::HT>(sg, Wb, o.v[OFF_WST], nxt<N, OFF_WM0T>(sg, Wb, o), as_,
                                          AVC_REVERSE(am, L::P_HM, L::P_GBHM, L::P_GAM, L::P_ABM));
-        layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0T], first, am, AVC_REVERSE(am0, L::P_H1, L::P_GBH1, L::P_GA1, L::P_AB1));
+        layer_sq<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0T], first, am, AVC_REVERSE(am0, L::P_H1, L::P_GBH1, L::P_GA1, L::P_AB1));
       }
     }
   }

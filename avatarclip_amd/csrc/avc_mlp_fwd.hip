@@ -59,6 +59,7 @@ struct FwdScratch {
   static constexpr int S_FEAT = S_HM + N::NMID * N::HK;   // feature vector, parked across the normal sweep
   static constexpr int S_KSTEPS = S_FEAT + N::HK;
 };
+struct FP1 { h8 a0, a1; };   // two k-steps of a parked activation (loaded one MFMA chain before their epilogue)
 template <typename P> __device__ __forceinline__ P launder_ptr(P p) {
   asm volatile("" : "+s"(p));
   return p;
@@ -154,20 +155,20 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
     float n[3];
     {
 #define AVC_F_NSTEP(OUT, SH)                                                                              \
-  AVC_EPI(const h8 hv0 = scr[((SH) + 2 * t) * 64], hv1 = scr[((SH) + 2 * t + 1) * 64];                     \
-          _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                   \
-            OUT[2 * t][j] = (_Float16)(acc[j] * sig_from_h((float)hv0[j]));                                 \
-            OUT[2 * t + 1][j] = (_Float16)(acc[8 + j] * sig_from_h((float)hv1[j])); }                       \
+  AVC_PRE(FP1 d; d.a0 = scr[((SH) + 2 * t) * 64]; d.a1 = scr[((SH) + 2 * t + 1) * 64]; return d;),         \
+  AVC_EPID(FP1, _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                             \
+            OUT[2 * t][j] = (_Float16)(acc[j] * sig_from_h((float)d.a0[j]));                                \
+            OUT[2 * t + 1][j] = (_Float16)(acc[8 + j] * sig_from_h((float)d.a1[j])); }                      \
           pin2(OUT[2 * t], OUT[2 * t + 1]);)
       h8 g[N::HK];
       h8 g2[N::HK];
       if constexpr (N::NMID == 2) {
-        layer_s<h8, N::SK, N::HT>(sg, Wf, o.v[OFF_WST], nxt<N, OFF_WM1T>(sg, Wf, o), g_s, AVC_F_NSTEP(g, L::S_HM + N::HK));
-        layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1T], nxt<N, OFF_WM0T>(sg, Wf, o), g, AVC_F_NSTEP(g2, L::S_HM));
-        layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0T], nxt<N, OFF_W0T>(sg, Wf, o), g2, AVC_F_NSTEP(g, L::S_H1));
+        layer_sq<h8, N::SK, N::HT>(sg, Wf, o.v[OFF_WST], nxt<N, OFF_WM1T>(sg, Wf, o), g_s, AVC_F_NSTEP(g, L::S_HM + N::HK));
+        layer_sq<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1T], nxt<N, OFF_WM0T>(sg, Wf, o), g, AVC_F_NSTEP(g2, L::S_HM));
+        layer_sq<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0T], nxt<N, OFF_W0T>(sg, Wf, o), g2, AVC_F_NSTEP(g, L::S_H1));
       } else {
-        layer_s<h8, N::SK, N::HT>(sg, Wf, o.v[OFF_WST], nxt<N, OFF_WM0T>(sg, Wf, o), g_s, AVC_F_NSTEP(g2, L::S_HM));
-        layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0T], nxt<N, OFF_W0T>(sg, Wf, o), g2, AVC_F_NSTEP(g, L::S_H1));
+        layer_sq<h8, N::SK, N::HT>(sg, Wf, o.v[OFF_WST], nxt<N, OFF_WM0T>(sg, Wf, o), g_s, AVC_F_NSTEP(g2, L::S_HM));
+        layer_sq<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0T], nxt<N, OFF_W0T>(sg, Wf, o), g2, AVC_F_NSTEP(g, L::S_H1));
       }
       float part[3] = {0.f, 0.f, 0.f};
       const auto wpe = T + o.v[OFF_WL0_PE] + h * 24;

@@ -97,6 +97,16 @@ template <typename T> __device__ __forceinline__ const AVC_GLOBAL T* as_global(c
 }
 template <typename T> __device__ __forceinline__ AVC_GLOBAL T* as_global(T* p) { return (AVC_GLOBAL T*)(p); }
 
+// Streaming traffic (parked activations, weight-gradient panels): written once, read once or a few times much later, far larger
+// than the 4 MB L2 of an XCD.  Non-temporal accesses keep it from evicting the packed weights every workgroup re-reads.
+#ifndef AVC_NO_NT
+#define AVC_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#define AVC_NT_LOAD(p) __builtin_nontemporal_load((p))
+#else
+#define AVC_NT_STORE(v, p) (*(p) = (v))
+#define AVC_NT_LOAD(p) (*(p))
+#endif
+
 // packed per-tile fp32 table [tile][half][16] -> this lane's 16 values
 __device__ __forceinline__ void load16(const float* __restrict__ tab, int t, int h, float (&out)[16]) {
   const AVC_GLOBAL f4* p = as_global(reinterpret_cast<const f4*>(tab + (t * 2 + h) * 16));

@@ -96,8 +96,8 @@ __device__ __forceinline__ void panel_store(b8* __restrict__ panel_blk, int tile
 #pragma unroll
   for (int j = 0; j < 8; ++j) { k0[j] = (__bf16)acc[j]; k1[j] = (__bf16)acc[8 + j]; }
   b8* dst = panel_blk + (long)tile * 128 + lane;
-  dst[0] = k0;
-  dst[64] = k1;
+  AVC_NT_STORE(k0, &dst[0]);
+  AVC_NT_STORE(k1, &dst[64]);
 }
 template <typename V>
 __device__ __forceinline__ V zero_frag() {
@@ -125,8 +125,8 @@ __device__ __forceinline__ void pstore(b8* __restrict__ panel_blk, bool live, in
   for (int j = 0; j < 8; ++j) { k0[j] = (__bf16)acc[j]; k1[j] = (__bf16)acc[8 + j]; }
   if (live) {
     b8* dst = panel_blk + (long)tile * 128 + lane;
-    dst[0] = k0;
-    dst[64] = k1;
+    AVC_NT_STORE(k0, &dst[0]);
+    AVC_NT_STORE(k1, &dst[64]);
   }
 }
 
@@ -135,7 +135,7 @@ __device__ __forceinline__ void pstore(b8* __restrict__ panel_blk, bool live, in
 // selection fragments pick the point column.  Values come back exactly as stored (bf16).
 __device__ __forceinline__ facc punpack(const b8* __restrict__ panel_blk, int tile, int lane, const b8& e0, const b8& e1) {
   const b8* src = panel_blk + (long)tile * 128 + lane;
-  const b8 k0 = src[0], k1 = src[64];
+  const b8 k0 = AVC_NT_LOAD(&src[0]), k1 = AVC_NT_LOAD(&src[64]);
   facc acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -155,8 +155,8 @@ struct PF3 { b8 a0, a1, b0, b1, c0, c1; };
 __device__ __forceinline__ PF1 pfetch1(const b8* __restrict__ panel_blk, int tile, int lane) {
   const b8* src = panel_blk + (long)tile * 128 + lane;
   PF1 d;
-  d.a0 = src[0];
-  d.a1 = src[64];
+  d.a0 = AVC_NT_LOAD(&src[0]);
+  d.a1 = AVC_NT_LOAD(&src[64]);
   return d;
 }
 __device__ __forceinline__ PF3 pfetch3(const b8* __restrict__ panel_blk, int ta, int tb, int tc, int lane) {
@@ -164,9 +164,9 @@ __device__ __forceinline__ PF3 pfetch3(const b8* __restrict__ panel_blk, int ta,
   const b8* sb = panel_blk + (long)tb * 128 + lane;
   const b8* sc = panel_blk + (long)tc * 128 + lane;
   PF3 d;
-  d.a0 = sa[0]; d.a1 = sa[64];
-  d.b0 = sb[0]; d.b1 = sb[64];
-  d.c0 = sc[0]; d.c1 = sc[64];
+  d.a0 = AVC_NT_LOAD(&sa[0]); d.a1 = AVC_NT_LOAD(&sa[64]);
+  d.b0 = AVC_NT_LOAD(&sb[0]); d.b1 = AVC_NT_LOAD(&sb[64]);
+  d.c0 = AVC_NT_LOAD(&sc[0]); d.c1 = AVC_NT_LOAD(&sc[64]);
   return d;
 }
 // ... and the un-transposition at the point of use
@@ -438,8 +438,8 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
           if (r < 8) { k0[r] = (__bf16)v; o0[r] = (__bf16)one; } else { k1[r - 8] = (__bf16)v; o1[r - 8] = (__bf16)one; }
         }
       }
-      b8* dd1 = pblk + (long)L::P_SDF * 128 + lane; dd1[0] = k0; dd1[64] = k1;
-      b8* dd2 = pblk + (long)L::P_ONE * 128 + lane; dd2[0] = o0; dd2[64] = o1;
+      b8* dd1 = pblk + (long)L::P_SDF * 128 + lane; AVC_NT_STORE(k0, &dd1[0]); AVC_NT_STORE(k1, &dd1[64]);
+      b8* dd2 = pblk + (long)L::P_ONE * 128 + lane; AVC_NT_STORE(o0, &dd2[0]); AVC_NT_STORE(o1, &dd2[64]);
     }
     // ------------------------------------------------------------------ phase E: second-order sweep (i) (bf16)
     {

@@ -50,7 +50,8 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_sdf_kernel(PointSrc ps, long
 // per-wavefront slot (frag layout, one coalesced 1-KiB store per k-step, 64 KiB per 32 points incl. the feature vector
 // instead of ~217 KiB of spill traffic; 2048 slots = 134 MB, inside the 256 MB Infinity Cache) and read back tile by tile in the epilogues of the
 // sweep; h_s never leaves the registers (it is consumed at once by g_a,s and by the feature layer).
-// Persistent workgroups (the slot is reused for every block a wave processes).
+// Persistent workgroups (the slot is reused for every block a wave processes).  Plain (temporal) accesses: the slot is
+// re-read within the same block, and non-temporal hints measured 5 % slower here (they pay off in the backward kernel).
 // ---------------------------------------------------------------------------------------------------------------
 template <class N>
 struct FwdScratch {
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
   AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
           _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);  \
           acc_to_frags(a, OUT[2 * t], OUT[2 * t + 1]);                                        \
-          AVC_NT_STORE(OUT[2 * t], &scr[((SCR) + 2 * t) * 64]); AVC_NT_STORE(OUT[2 * t + 1], &scr[((SCR) + 2 * t + 1) * 64]);)
+          scr[((SCR) + 2 * t) * 64] = OUT[2 * t]; scr[((SCR) + 2 * t + 1) * 64] = OUT[2 * t + 1];)
 #define AVC_F_LAST(OFFB)                                                                      \
   AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
           _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);  \
@@ -148,14 +149,14 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
         _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = acc[r] + b[r];
         h8 f0, f1;
         acc_to_frags(a, f0, f1);
-        AVC_NT_STORE(f0, &scr[(L::S_FEAT + 2 * t) * 64]); AVC_NT_STORE(f1, &scr[(L::S_FEAT + 2 * t + 1) * 64]);
+        scr[(L::S_FEAT + 2 * t) * 64] = f0; scr[(L::S_FEAT + 2 * t + 1) * 64] = f1;
       ));
     }
     // ---------------------------------------------------------------- normal sweep: g_h(prev) = W^T g_a ; g_a(prev) = g_h sigma(h_prev)
     float n[3];
     {
 #define AVC_F_NSTEP(OUT, SH)                                                                              \
-  AVC_PRE(FP1 d; d.a0 = AVC_NT_LOAD(&scr[((SH) + 2 * t) * 64]); d.a1 = AVC_NT_LOAD(&scr[((SH) + 2 * t + 1) * 64]); return d;), \
+  AVC_PRE(FP1 d; d.a0 = scr[((SH) + 2 * t) * 64]; d.a1 = scr[((SH) + 2 * t + 1) * 64]; return d;),         \
   AVC_EPID(FP1, _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                             \
             OUT[2 * t][j] = (_Float16)(acc[j] * sig_from_h((float)d.a0[j]));                                \
             OUT[2 * t + 1][j] = (_Float16)(acc[8 + j] * sig_from_h((float)d.a1[j])); }                      \
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
       }
       h8 feat[N::HK];
 #pragma unroll
-      for (int s = 0; s < N::HK; ++s) feat[s] = AVC_NT_LOAD(&scr[(L::S_FEAT + s) * 64]);
+      for (int s = 0; s < N::HK; ++s) feat[s] = scr[(L::S_FEAT + s) * 64];
 #define AVC_F_RELU(OFFB, OUT)                                                                 \
   AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
           _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r] + b[r], 0.f);   \

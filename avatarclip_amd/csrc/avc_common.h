@@ -99,11 +99,14 @@ template <typename T> __device__ __forceinline__ AVC_GLOBAL T* as_global(T* p) {
 
 // Streaming traffic (parked activations, weight-gradient panels): written once, read once or a few times much later, far larger
 // than the 4 MB L2 of an XCD.  Non-temporal accesses keep it from evicting the packed weights every workgroup re-reads.
-#ifndef AVC_NO_NT
+#ifndef AVC_NO_NT_STORE
 #define AVC_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
-#define AVC_NT_LOAD(p) __builtin_nontemporal_load((p))
 #else
 #define AVC_NT_STORE(v, p) (*(p) = (v))
+#endif
+#ifndef AVC_NO_NT_LOAD
+#define AVC_NT_LOAD(p) __builtin_nontemporal_load((p))
+#else
 #define AVC_NT_LOAD(p) (*(p))
 #endif
 

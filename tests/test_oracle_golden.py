@@ -88,3 +88,23 @@ def test_rays_and_cameras():
         assert np.allclose(O.lookat(eye, at, np.array([0, 1, 0])), pose, atol=1e-6)
     for i in range(6):
         assert np.allclose(O.sphere_coord(0.3 * i, 0.7 * i), z["sphere_coord"][i])
+
+
+def test_gen_rays_silhouettes_matches_reference_golden():
+    """SMPL_Dataset.gen_rays_silhouettes (dataset.py:252-275) with the dilation done as a 21x21 max filter on the
+    device instead of scipy on the host: same rays, same grid size, same mask as the reference's own function."""
+    import os
+    from avatarclip_amd.dataset import SMPL_Dataset
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "rays_sil.npz"))
+    ds = SMPL_Dataset(None, device=torch.device("cpu"), load_images=False)
+    assert abs(ds.focal - float(z["focal"])) < 1e-9
+    pose = torch.from_numpy(z["pose"])
+    for i in range(2):
+        o, v, Wn, sel = ds.gen_rays_silhouettes(pose, int(z["max_ray_num%d" % i]), torch.from_numpy(z["mask%d" % i]))
+        assert Wn == int(z["W%d" % i])
+        assert torch.equal(sel.cpu(), torch.from_numpy(z["sel%d" % i]))
+        assert o.shape == z["rays_o%d" % i].shape
+        assert np.allclose(o.numpy(), z["rays_o%d" % i], atol=1e-6) and np.allclose(v.numpy(), z["rays_v%d" % i], atol=1e-6)
+    # empty mask: the reference falls back to the level-4 full frame
+    o, v = ds.gen_rays_silhouettes(pose, 1000, torch.zeros(256, 256))
+    assert o.shape == (64, 64, 3)

@@ -170,3 +170,29 @@ def test_runner_train_neus_init_and_checkpoint_round_trip(tmp_path):
     sd_now = {k: v.clone() for k, v in blob["sdf_network_fine"].items()}
     for k, v in r2.sdf_network.state_dict().items():
         assert torch.equal(v.cpu(), sd_now[k].cpu())
+
+
+@gpu
+def test_train_clip_iteration_with_silhouette_rays_and_background_augmentation():
+    """the reference's default sampling mode (use_silhouettes = True, main.py:360-375): a ragged, per-iteration ray set inside the
+    dilated SMPL silhouette, scattered back into the image for CLIP, with every background augmentation (main.py:387-415)"""
+    import bench
+    from avatarclip_amd.runner import Runner
+    conf = bench.make_conf(256, 32, small=True)
+    conf.put("train.use_silhouettes", True)
+    conf.put("train.max_ray_num", 3000)
+    conf.put("train.warm_up_end", 0)
+    torch.manual_seed(0)
+    np.random.seed(3)
+    r = Runner(None, mode="train_clip", conf=conf, device=torch.device("cuda"))
+    r.init_clip()
+    r.init_smpl()
+    r.update_learning_rate()
+    seen = set()
+    for i in range(8):
+        loss = r.train_clip_iteration(i)
+        assert torch.isfinite(loss), i
+        seen.add(int(r.last_stats["rays"]))
+        r.update_learning_rate()
+    assert len(seen) > 1 and max(seen) <= 3000 * 1.3      # ragged ray counts that respect the budget
+    assert all(torch.isfinite(p).all() for p in r.params_to_train)

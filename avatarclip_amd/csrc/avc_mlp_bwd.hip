@@ -112,7 +112,12 @@ __device__ __forceinline__ V zero_frag() {
 // LDS, the epilogue of tile t-1 (activation, panel transposition, scratch parking) is issued under the MFMAs of tile t.
 // `live` = this wavefront owns a real 32-point block (waves past the end still walk the tile sequence for the barriers).
 
-template <typename V>
+// KEEP = the tile is read back by a later sweep of the same block: normal cache policy (it may still be in L2);
+// otherwise the tile is only read by the weight-gradient kernel, much later: non-temporal, does not displace the weights.
+#ifndef PANEL_KEEP
+#define PANEL_KEEP true
+#endif
+template <typename V, bool KEEP>
 __device__ __forceinline__ void pstore(b8* __restrict__ panel_blk, bool live, int tile, int lane, const V& f0, const V& f1,
                                        const V& e0, const V& e1) {
   facc acc;
@@ -125,8 +130,13 @@ __device__ __forceinline__ void pstore(b8* __restrict__ panel_blk, bool live, in
   for (int j = 0; j < 8; ++j) { k0[j] = (__bf16)acc[j]; k1[j] = (__bf16)acc[8 + j]; }
   if (live) {
     b8* dst = panel_blk + (long)tile * 128 + lane;
-    AVC_NT_STORE(k0, &dst[0]);
-    AVC_NT_STORE(k1, &dst[64]);
+    if (KEEP) {
+      dst[0] = k0;
+      dst[64] = k1;
+    } else {
+      AVC_NT_STORE(k0, &dst[0]);
+      AVC_NT_STORE(k1, &dst[64]);
+    }
   }
 }
 
@@ -227,8 +237,8 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
     pe_compute(x, h, pe);
     h8 pef[3];
     pe_to_frags_f16(pe, x, h, pef);
-    pstore<h8>(pblk, live, L::P_H0, lane, pef[0], pef[1], e0h, e1h);
-    pstore<h8>(pblk, live, L::P_H0 + 1, lane, pef[2], zero_frag<h8>(), e0h, e1h);
+    pstore<h8, false>(pblk, live, L::P_H0, lane, pef[0], pef[1], e0h, e1h);
+    pstore<h8, false>(pblk, live, L::P_H0 + 1, lane, pef[2], zero_frag<h8>(), e0h, e1h);
     // Register discipline: nothing but x, n, nbar, d_sdf survives a phase.  Every activation goes out as a panel and is
     // read back (punpack) / re-computed (positional encoding) where it is needed again; this keeps each phase at
     // "input + output + accumulators" and leaves registers for pipelining the LDS operand reads.
@@ -238,20 +248,20 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
   AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
           _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);  \
           acc_to_frags(a, OUT[2 * t], OUT[2 * t + 1]);                                        \
-          pstore<h8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0h, e1h);)
+          pstore<h8, PANEL_KEEP>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0h, e1h);)
       // last trunk layer: h_s goes out as a panel only; the registers keep g_a,s
 #define AVC_FWD_LAST(OFFB, PT, PG)                                                            \
   AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
           _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);  \
           h8 hs0, hs1; acc_to_frags(a, hs0, hs1);                                             \
-          pstore<h8>(pblk, live, (PT) + t, lane, hs0, hs1, e0h, e1h);                         \
+          pstore<h8, PANEL_KEEP>(pblk, live, (PT) + t, lane, hs0, hs1, e0h, e1h);                         \
           float w0[8], w1[8];                                                                 \
           load8(T + o.v[OFF_WL0_FRAG], 2 * t, h, w0); load8(T + o.v[OFF_WL0_FRAG], 2 * t + 1, h, w1); \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                     \
             g_s[2 * t][j] = (_Float16)(w0[j] * sig_from_h(a[j]));                             \
             g_s[2 * t + 1][j] = (_Float16)(w1[j] * sig_from_h(a[8 + j])); }                   \
           pin2(g_s[2 * t], g_s[2 * t + 1]);                                                   \
-          pstore<h8>(pblk, live, (PG) + t, lane, g_s[2 * t], g_s[2 * t + 1], e0h, e1h);)
+          pstore<h8, PANEL_KEEP>(pblk, live, (PG) + t, lane, g_s[2 * t], g_s[2 * t + 1], e0h, e1h);)
       h8 h1[N::HK];
       layer_s<h8, 3, N::HT>(sg, Wf, o.v[OFF_W0], nxt<N, OFF_WM0>(sg, Wf, o), pef,
                                    AVC_FWD_KEEP(OFF_B0, h1, L::P_H1));
@@ -282,7 +292,7 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
             OUT[2 * t][j] = (_Float16)(acc[j] * sig_from_h(hv[j]));                                         \
             OUT[2 * t + 1][j] = (_Float16)(acc[8 + j] * sig_from_h(hv[8 + j])); }                           \
           pin2(OUT[2 * t], OUT[2 * t + 1]);                                                                 \
-          pstore<h8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0h, e1h);)
+          pstore<h8, PANEL_KEEP>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0h, e1h);)
       h8 g[N::HK];
       h8 g2[N::HK];
       if constexpr (N::NMID == 2) {
@@ -332,7 +342,7 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
         load16(T + o.v[OFF_BL], t, h, b);
         _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = acc[r] + b[r];
         acc_to_frags(a, feat[2 * t], feat[2 * t + 1]);
-        pstore<h8>(pblk, live, L::P_FEAT + t, lane, feat[2 * t], feat[2 * t + 1], e0h, e1h);
+        pstore<h8, false>(pblk, live, L::P_FEAT + t, lane, feat[2 * t], feat[2 * t + 1], e0h, e1h);
         ));
       }
       h8 xn[1];
@@ -341,7 +351,7 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
 #pragma unroll
         for (int c = 0; c < 3; ++c) { xn[0][c] = (_Float16)x[c]; xn[0][3 + c] = (_Float16)n[c]; }
       }
-      pstore<h8>(pblk, live, L::P_XN, lane, xn[0], zero_frag<h8>(), e0h, e1h);
+      pstore<h8, false>(pblk, live, L::P_XN, lane, xn[0], zero_frag<h8>(), e0h, e1h);
 #define AVC_RELU_KEEP(OFFB, OUT, MSK, PT)                                                    \
   AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
           unsigned bits = 0u;                                                                 \
@@ -349,7 +359,7 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
             a[r] = fmaxf(acc[r] + b[r], 0.f); bits |= (a[r] > 0.f ? 1u : 0u) << r; }          \
           MSK[t * 64] = (unsigned short)bits;                                                 \
           acc_to_frags(a, OUT[2 * t], OUT[2 * t + 1]);                                        \
-          pstore<h8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0h, e1h);)
+          pstore<h8, false>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0h, e1h);)
       h8 r1[N::HK];
       h8 r2[N::HK];
       if constexpr (N::NCMID == 1) {
@@ -382,14 +392,14 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
       dof[0] = zero_frag<b8>();
 #pragma unroll
       for (int r = 0; r < 4; ++r) dof[0][r] = (__bf16)delta_o[r];
-      pstore<b8>(pblk, live, L::P_DO, lane, dof[0], zero_frag<b8>(), e0b, e1b);
+      pstore<b8, false>(pblk, live, L::P_DO, lane, dof[0], zero_frag<b8>(), e0b, e1b);
 #define AVC_RELU_BWD(OUT, MSK, PT)                                                                         \
   AVC_EPI(const unsigned bits = MSK[t * 64];                                                                 \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                    \
             OUT[2 * t][j] = (__bf16)(((bits >> j) & 1u) ? acc[j] : 0.f);                                     \
             OUT[2 * t + 1][j] = (__bf16)(((bits >> (8 + j)) & 1u) ? acc[8 + j] : 0.f); }                     \
           pin2(OUT[2 * t], OUT[2 * t + 1]);                                                                  \
-          pstore<b8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0b, e1b);)
+          pstore<b8, false>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0b, e1b);)
       b8 dl[N::HK];
       b8 d1[N::HK];
       if constexpr (N::NCMID == 1) {
@@ -410,7 +420,7 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
             dfeat[2 * (t < N::HT ? t : 0) + 1][j] = (__bf16)acc[8 + j];
           }
           pin2(dfeat[2 * (t < N::HT ? t : 0)], dfeat[2 * (t < N::HT ? t : 0) + 1]);
-          pstore<b8>(pblk, live, L::P_DFEAT + t, lane, dfeat[2 * (t < N::HT ? t : 0)], dfeat[2 * (t < N::HT ? t : 0) + 1], e0b, e1b);
+          pstore<b8, PANEL_KEEP>(pblk, live, L::P_DFEAT + t, lane, dfeat[2 * (t < N::HT ? t : 0)], dfeat[2 * (t < N::HT ? t : 0) + 1], e0b, e1b);
         } else {
           dn_acc[0] = acc[3]; dn_acc[1] = acc[0]; dn_acc[2] = acc[1];
         }
@@ -450,8 +460,8 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
 #pragma unroll
         for (int q = 0; q < 24; ++q) gb0[q >> 3][q & 7] = (__bf16)(pe4.d[q] * nbar[q % 3]);
       }
-      pstore<b8>(pblk, live, L::P_GB0, lane, gb0[0], gb0[1], e0b, e1b);
-      pstore<b8>(pblk, live, L::P_GB0 + 1, lane, gb0[2], zero_frag<b8>(), e0b, e1b);
+      pstore<b8, false>(pblk, live, L::P_GB0, lane, gb0[0], gb0[1], e0b, e1b);
+      pstore<b8, false>(pblk, live, L::P_GB0 + 1, lane, gb0[2], zero_frag<b8>(), e0b, e1b);
       // gbar_a = W gbar_h(in); gbar_h(out) = gbar_a * sigma(h_out)
 #define AVC_SECOND(OUT, PH, PT)                                                                             \
   AVC_PRE(return pfetch1(pblk, (PH) + t, lane);),                                                            \
@@ -460,7 +470,7 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
             OUT[2 * t][j] = (__bf16)(acc[j] * sig_from_h(hv[j]));                                            \
             OUT[2 * t + 1][j] = (__bf16)(acc[8 + j] * sig_from_h(hv[8 + j])); }                              \
           pin2(OUT[2 * t], OUT[2 * t + 1]);                                                                  \
-          pstore<b8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0b, e1b);)
+          pstore<b8, PANEL_KEEP>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0b, e1b);)
       b8 gb1[N::HK];
       layer_sqd<b8, 3, N::HT>(sg, Wb, o.v[OFF_W0G], nxt<N, OFF_WM0>(sg, Wb, o), gb0,
                                    AVC_SECOND(gb1, L::P_H1, L::P_GBH1));
@@ -501,7 +511,7 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
           as_[2 * t + 1][j] = (__bf16)(second_term(bv[8 + j], gv[8 + j], s1) + (acc[8 + j] + wa[8 + j] * dsdfS) * s1);
         }
         pin2(as_[2 * t], as_[2 * t + 1]);
-        pstore<b8>(pblk, live, L::P_ABS + t, lane, as_[2 * t], as_[2 * t + 1], e0b, e1b);
+        pstore<b8, false>(pblk, live, L::P_ABS + t, lane, as_[2 * t], as_[2 * t + 1], e0b, e1b);
       ));
       // hbar(prev) = W^T abar(cur); abar(prev) = abar'(prev) + hbar * sigma(h_prev)
 #define AVC_REVERSE(OUT, PH, PB, PG, PT)                                                                    \
@@ -514,7 +524,7 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
             OUT[2 * t][j] = (__bf16)(second_term(bv[j], gv[j], s0) + acc[j] * s0);                           \
             OUT[2 * t + 1][j] = (__bf16)(second_term(bv[8 + j], gv[8 + j], s1) + acc[8 + j] * s1); }         \
           pin2(OUT[2 * t], OUT[2 * t + 1]);                                                                  \
-          pstore<b8>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0b, e1b);)
+          pstore<b8, false>(pblk, live, (PT) + t, lane, OUT[2 * t], OUT[2 * t + 1], e0b, e1b);)
       b8 am[N::HK];
       b8 am0[N::HK];
       const Next first = nxt<N, OFF_W0>(sg, Wf0, o);   // prefetch the first tile of the next block iteration

@@ -17,7 +17,9 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # AVC_DIST_BACKEND=gloo: development aid (two ranks on ONE GPU to exercise the multi-rank path where RCCL
+            # refuses duplicate devices); the product default on GPUs is "nccl" = RCCL
+            backend = os.environ.get("AVC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -158,6 +158,8 @@ def main():
     from avatarclip_amd.runner import Runner
     rank, world, local_rank = parallel.init_from_env()
     assert world == max(args.gpus, 1) or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    if os.environ.get("AVC_SINGLE_DEVICE"):      # development aid: all ranks on device 0 (see parallel.init_from_env)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     torch.manual_seed(0)             # identical initial weights on every rank

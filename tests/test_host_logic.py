@@ -149,3 +149,26 @@ def test_gaussian_blur_matches_depthwise_convolution():
     out = _gaussian_blur(x, ksize, sigma)
     assert out.shape == x.shape
     assert (out - ref).abs().max() < 1e-6
+
+
+def test_conf_parser_reads_every_reference_conf():
+    """the reference's own conf files (pyhocon syntax) parse with our HOCON subset and carry every key Runner reads.
+    Runs only where the reference checkout is mounted (the build container)."""
+    import glob
+    import os
+    from avatarclip_amd.conf import ConfigFactory
+    root = "/root/reference/AvatarGen/AppearanceGen/confs"
+    files = sorted(glob.glob(os.path.join(root, "**", "*.conf"), recursive=True))
+    if not files:
+        pytest.skip("reference checkout not present")
+    for f in files:
+        text = open(f).read().replace("CASE_NAME", "case")
+        c = ConfigFactory.parse_string(text)
+        assert c.get_string("general.base_exp_dir")
+        assert c.get_int("train.end_iter") > 0 and c.get_float("train.learning_rate") > 0
+        assert c.get_int("model.sdf_network.d_hidden") in (128, 256)
+        assert c.get_int("model.neus_renderer.n_samples") > 0 and c.get_int("model.neus_renderer.up_sample_steps") == 4
+        sk = c["model.sdf_network"]["skip_in"]
+        assert list(sk) == [c.get_int("model.sdf_network.n_layers")]
+        if "clip" in c:
+            assert isinstance(c.get_string("clip.prompt"), str) and len(c.get_string("clip.prompt")) > 3

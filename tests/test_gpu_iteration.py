@@ -118,7 +118,8 @@ def test_train_clip_iteration_matches_oracle_driven_iteration():
 
 
 @gpu
-def test_runner_train_neus_init_and_checkpoint_round_trip(tmp_path):
+@pytest.mark.parametrize("extra_color", [True, False])
+def test_runner_train_neus_init_and_checkpoint_round_trip(tmp_path, extra_color):
     """Runner.train (main.py:180-256, BASELINE config 1) on a synthetic 4-image dataset in the reference's on-disk format
     (transforms_train.json + PNGs): the loss falls, the checkpoint has the reference's keys (main.py:622-629) and resumes."""
     import json
@@ -149,11 +150,15 @@ def test_runner_train_neus_init_and_checkpoint_round_trip(tmp_path):
     conf.put("train.batch_size", 256)
     conf.put("train.warm_up_end", 0)
     conf.put("train.save_freq", 30)
+    # confs/base_models/*.conf (the NeuS-init stage) have no extra colour head; confs/examples/*.conf do
+    conf.put("model.rendering_network.extra_color", extra_color)
+    conf.put("model.neus_renderer.extra_color", extra_color)
     torch.manual_seed(0)
     np.random.seed(0)
     dev = torch.device("cuda")
     runner = Runner(None, mode="train", conf=conf, device=dev)
     assert runner.dataset.n_images == 4
+    assert ("extra_lin.weight_v" in runner.color_network.state_dict()) == extra_color
     first = runner.train_iteration(runner.dataset.gen_random_rays_at(0, 256)).item()
     runner.train()
     last = runner.train_iteration(runner.dataset.gen_random_rays_at(0, 256)).item()

@@ -164,3 +164,42 @@ def test_128spp_render_matches_oracle_on_identical_depths():
         e = (out[k].cpu() - ref[k].detach()).abs()
         print(k, "max", e.max().item(), "mean", e.mean().item())
         assert e.max() < 2e-2 and e.mean() < 1.5e-3, k
+
+
+@gpu
+def test_render_without_extra_color_head_matches_oracle():
+    """confs/base_models/*.conf (NeuS-init stage): RenderingNetwork without `extra_lin`, NeuSRenderer(extra_color=False):
+    forward and parameter gradients vs the oracle on identical depths (small nets)."""
+    from avatarclip_amd import fields, renderer
+    dev = torch.device("cuda")
+    torch.manual_seed(1)
+    sdf = fields.SDFNetwork(d_out=129, d_in=3, d_hidden=128, n_layers=3, skip_in=[3], multires=6, bias=0.5, scale=1.0,
+                            geometric_init=True, weight_norm=True).to(dev)
+    col = fields.RenderingNetwork(d_feature=128, mode="no_view_dir", d_in=6, d_out=3, d_hidden=128, n_layers=1,
+                                  weight_norm=True, multires_view=0, squeeze_out=True, extra_color=False).to(dev)
+    var = fields.SingleVarianceNetwork(0.3).to(dev)
+    ren = renderer.NeuSRenderer(None, sdf, var, col, 16, 16, 0, 4, 1.0, False)
+    ro, rd, near, far = [t.contiguous() for t in _view(12, dev)]
+    R = ro.shape[0]
+    sd_s = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in sdf.named_parameters()}
+    sd_c = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in col.named_parameters()}
+    vv = var.variance.detach().cpu().clone().requires_grad_(True)
+    jitter = torch.rand(R, 1, generator=torch.Generator().manual_seed(4))
+    ref = O.render(sd_s, sd_c, vv, ro.cpu(), rd.cpu(), near.cpu(), far.cpu(), 16, 16, 4, jitter, torch.ones(1, 3), 1.0,
+                   extra_color=False)
+    out = ren.render(ro, rd, near, far, background_rgb=torch.ones(1, 3, device=dev), cos_anneal_ratio=1.0,
+                     z_vals=ref["z_vals"].detach().to(dev))
+    e = (out["color_fine"].detach().cpu() - ref["color_fine"].detach()).abs()
+    print("color max", e.max().item(), "mean", e.mean().item())
+    assert e.max() < 2e-2 and e.mean() < 1.5e-3
+    w = torch.randn(R, 3, generator=torch.Generator().manual_seed(6))
+    (ref["color_fine"] * w).sum().add(ref["gradient_error"]).backward()
+    (out["color_fine"] * w.to(dev)).sum().add(out["gradient_error"]).backward()
+    for name, net, sd in (("sdf", sdf, sd_s), ("col", col, sd_c)):
+        for n_, p in net.named_parameters():
+            g_ref = sd[n_].grad
+            if g_ref is None or g_ref.abs().max() < 1e-7:
+                continue
+            g = p.grad.detach().cpu()
+            rel = ((g - g_ref).double().norm() / g_ref.double().norm()).item()
+            assert rel < 3e-2, (name, n_, rel)

@@ -201,3 +201,28 @@ def test_train_clip_iteration_with_silhouette_rays_and_background_augmentation()
         r.update_learning_rate()
     assert len(seen) > 1 and max(seen) <= 3000 * 1.3      # ragged ray counts that respect the budget
     assert all(torch.isfinite(p).all() for p in r.params_to_train)
+
+
+@gpu
+@pytest.mark.parametrize("flags", [dict(add_no_texture=False, texture_cast_light=False, use_face_prompt=False, use_back_prompt=False),
+                                   dict(add_no_texture=False, texture_cast_light=True, use_face_prompt=True, use_back_prompt=False),
+                                   dict(add_no_texture=True, texture_cast_light=False, use_face_prompt=False, use_back_prompt=True)])
+def test_train_clip_ablation_switches(flags):
+    """the switch combinations of confs/ablation/*.conf (main.py:426-534): every branch of the shading / CLIP-loss glue runs"""
+    import bench
+    from avatarclip_amd.runner import Runner
+    conf = bench.make_conf(64, 32, small=True)
+    for k, v in flags.items():
+        conf.put("train." + k, v)
+    conf.put("train.use_bg_aug", False)
+    torch.manual_seed(0)
+    np.random.seed(5)
+    r = Runner(None, mode="train_clip", conf=conf, device=torch.device("cuda"))
+    r.init_clip()
+    r.init_smpl()
+    r.update_learning_rate()
+    for i in range(5):          # i = 0 and 4 take the face-prompt camera when enabled (iter_i % 4 == 0)
+        loss = r.train_clip_iteration(i)
+        assert torch.isfinite(loss), (flags, i)
+        r.update_learning_rate()
+    assert all(torch.isfinite(p).all() for p in r.params_to_train)

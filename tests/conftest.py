@@ -17,3 +17,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _libavc_is_built():
+    """Build libavc.so in-tree when it is missing or older than its sources (hipcc cross-compiles without a GPU; a no-op when
+    the library that travelled with the snapshot is current).  This only makes sure the ARTEFACT exists: the product path
+    still has no fallback and raises when it cannot load the library."""
+    try:
+        from avatarclip_amd import build
+        build.build()
+    except Exception as e:   # no hipcc on this machine: the tests that need the library will say so themselves
+        print("libavc build skipped:", e)
+    yield

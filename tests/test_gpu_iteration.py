@@ -177,6 +177,17 @@ def test_runner_train_neus_init_and_checkpoint_round_trip(tmp_path, extra_color)
     sd_now = {k: v.clone() for k, v in blob["sdf_network_fine"].items()}
     for k, v in r2.sdf_network.state_dict().items():
         assert torch.equal(v.cpu(), sd_now[k].cpu())
+    # --is_continue picks the newest checkpoint not past end_iter (main.py:160-170); train_clip's --pretrain path loads the
+    # three networks of a NeuS-init checkpoint into the CLIP stage (main.py:611-620, strict=False for the colour head)
+    r3 = Runner(None, mode="train", conf=conf, device=dev, is_continue=True)
+    assert r3.iter_step == 30
+    conf.put("train.pretrain", str(ck))
+    r4 = Runner(None, mode="train_clip", conf=conf, device=dev)
+    for k, v in r4.sdf_network.state_dict().items():
+        assert torch.equal(v.cpu(), sd_now[k].cpu())
+    # validate_image (main.py:741-820): one view rendered in ray chunks
+    img = r4.validate_image(idx=0, resolution_level=2)
+    assert img.shape == (16, 16, 3) and torch.isfinite(img).all() and img.min() >= 0 and img.max() <= 1
 
 
 @gpu

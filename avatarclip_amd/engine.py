@@ -72,7 +72,7 @@ class Engine:
     _by_net = weakref.WeakKeyDictionary()
     PROFILE = False               # bench.py: record (name, points, start_event, end_event) per kernel launch group
     prof_events = []
-    WG_NSPLIT = 512               # split-K workgroups per weight-gradient pair (2 per CU)
+    WG_NSPLIT = 256               # split-K workgroups per weight-gradient pair (one per CU; 512 and 1024 measured 1.5 % / 6 % slower: partial-slab traffic)
     MAX_FWD_WAVES = 2048          # persistent grid of avc_render_points_fwd: 256 CUs x one 8-wave workgroup
     MAX_BWD_WAVES = 2048          # 256 CUs x 4 wavefronts (one per SIMD: the backward kernel uses the full RF)
     PANEL_BYTES_BUDGET = 48 << 30  # weight-gradient operand panels per chunk of points (capped at half the free HBM)

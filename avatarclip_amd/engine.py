@@ -4,6 +4,7 @@
 There is deliberately no eager/CPU fallback in this file: without libavc.so or without a GPU the calls raise.
 """
 import ctypes
+import os
 import weakref
 
 import numpy as np
@@ -75,7 +76,8 @@ class Engine:
     WG_NSPLIT = 256               # split-K workgroups per weight-gradient pair (one per CU; 512 and 1024 measured 1.5 % / 6 % slower: partial-slab traffic)
     MAX_FWD_WAVES = 2048          # persistent grid of avc_render_points_fwd: 256 CUs x one 8-wave workgroup
     MAX_BWD_WAVES = 2048          # 256 CUs x 4 wavefronts (one per SIMD: the backward kernel uses the full RF)
-    PANEL_BYTES_BUDGET = 48 << 30  # weight-gradient operand panels per chunk of points (capped at half the free HBM)
+    # weight-gradient operand panels per chunk of points (capped at half the free HBM); AVC_PANEL_GIB overrides (tuning aid)
+    PANEL_BYTES_BUDGET = int(os.environ.get("AVC_PANEL_GIB", "96")) << 30
 
     def __init__(self, spec: PK.NetSpec, device):
         if device.type != "cuda":

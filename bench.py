@@ -203,12 +203,12 @@ def main():
             flops = 2.0 * F_PT * avg_pts          # forward recompute + every dX product (incl. double backward)
             # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_summary.md: FETCH_SIZE x2 + WRITE_SIZE,
             # separate rocprofv3 --pmc runs of this same command); scaled to this run's points per launch
-            traffic = 25.5e9 * avg_pts / 1048576.0
+            traffic = 25.7e9 * avg_pts / 1048576.0
             roof = {"kernel": "mlp_bwd_kernel (avc_render_points_bwd)", "bound": "mfma", "achieved": flops / avg_t / 1e12,
                     "peak": PEAK_MFMA / 1e12, "unit": "TFLOP/s", "frac": flops / avg_t / PEAK_MFMA, "traffic": traffic,
                     "traffic_note": "HBM bytes per launch from the rocprofv3 PMC passes of this command (profiles/r01_pmc_summary.md: "
-                                    "2 x FETCH_SIZE + WRITE_SIZE = 24.3 KiB/point); algorithmic bytes are the 11.25 KiB/point of "
-                                    "weight-gradient panels: the kernel runs at ~4.9 TB/s, i.e. it is HBM-bound, not MFMA-bound",
+                                    "2 x FETCH_SIZE + WRITE_SIZE = 24.5 KiB/point); algorithmic bytes are the 11.25 KiB/point of "
+                                    "weight-gradient panels: the kernel runs at ~5.0 TB/s, i.e. it is HBM-bound, not MFMA-bound",
                     "avg_launch_ms": avg_t * 1e3, "points_per_launch": avg_pts, "launches": len(recs),
                     "algorithmic_flop_per_point": 2.0 * F_PT}
         kern_ms = {k: 1e3 * float(np.sum([t for _, t in v])) / args.steps for k, v in per_kernel.items()}

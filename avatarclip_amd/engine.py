@@ -76,8 +76,8 @@ class Engine:
     WG_NSPLIT = 256               # split-K workgroups per weight-gradient pair (one per CU; 512 and 1024 measured 1.5 % / 6 % slower: partial-slab traffic)
     MAX_FWD_WAVES = 2048          # persistent grid of avc_render_points_fwd: 256 CUs x one 8-wave workgroup
     MAX_BWD_WAVES = 2048          # 256 CUs x 4 wavefronts (one per SIMD: the backward kernel uses the full RF)
-    # weight-gradient operand panels per chunk of points (capped at half the free HBM); AVC_PANEL_GIB overrides (tuning aid)
-    PANEL_BYTES_BUDGET = int(os.environ.get("AVC_PANEL_GIB", "96")) << 30
+    # weight-gradient operand panels per chunk of points (capped at 70 % of the free HBM); AVC_PANEL_GIB overrides (tuning aid)
+    PANEL_BYTES_BUDGET = int(os.environ.get("AVC_PANEL_GIB", "192")) << 30
 
     def __init__(self, spec: PK.NetSpec, device):
         if device.type != "cuda":
@@ -222,7 +222,7 @@ class Engine:
         R, S = z.shape
         per_ray_blocks = S / 32.0
         have = self._panels.numel() if self._panels is not None else 0
-        budget = max(min(self.PANEL_BYTES_BUDGET, (torch.cuda.mem_get_info(self.device)[0] + have) // 2), 1 << 28)
+        budget = max(min(self.PANEL_BYTES_BUDGET, (torch.cuda.mem_get_info(self.device)[0] + have) * 7 // 10), 1 << 28)
         max_blocks = max(1, budget // (self.ptiles * 2048))
         rays_per_chunk = max(1, int(max_blocks / per_ray_blocks) - 1)
         rays_per_chunk = min(rays_per_chunk, R)

@@ -179,6 +179,20 @@ class ClipVisionB32:
         return self._text.encode_text(tokens)
 
 
+def load_state_dict(path: str) -> Dict[str, torch.Tensor]:
+    """An OpenAI CLIP ViT-B/32 checkpoint: the TorchScript archive `ViT-B-32.pt` that `clip.load` downloads, a plain
+    `torch.save(model.state_dict())` file, or a .safetensors file with the same key names."""
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        return load_file(path)
+    try:
+        obj = torch.jit.load(path, map_location="cpu")
+    except RuntimeError:
+        obj = torch.load(path, map_location="cpu", weights_only=False)
+    sd = obj.state_dict() if hasattr(obj, "state_dict") else obj
+    return {k: v for k, v in sd.items() if torch.is_tensor(v)}
+
+
 def clip_preprocess(img_hw3: torch.Tensor) -> torch.Tensor:
     """main.py:261-267,510-511: RandomResizedCrop(224, scale=(1,1)) of a square image == bilinear resize
     (align_corners=False, no antialias); RandomPerspective(p=0) == identity; then Normalize."""

@@ -97,12 +97,16 @@ __device__ __forceinline__ void dephase(const ST& st) {
 }
 #define AVC_EPI(...) [&](int t, const facc& acc) __attribute__((always_inline)) { __VA_ARGS__ }
 
+#ifndef AVC_PAIR
+#define AVC_PAIR 1   // 1: two output tiles per MFMA stream (independent accumulators), 0: one dependent chain per tile
+#endif
 template <typename V, int KS, int NT, class ST, typename Epi>
 __device__ __forceinline__ void layer_s(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&in)[KS],
                                         Epi&& epi) {
   constexpr int G = ST::template group<KS>();
   constexpr int NG = (NT + G - 1) / G;
-  facc prev;
+  facc prev0, prev1;
+  int tp = -1, np = 0;   // first tile / number of tiles whose epilogue is pending (compile-time after unrolling)
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     AVC_SYNC();   // group g has landed (hipcc drains vmcnt before the barrier); the other buffer is free
@@ -116,18 +120,28 @@ __device__ __forceinline__ void layer_s(ST& st, const V* __restrict__ blob, int 
     }
     dephase(st);
 #pragma unroll
-    for (int j = 0; j < G; ++j) {
+    for (int j = 0; j < G; j += (AVC_PAIR ? 2 : 1)) {
       const int t = g * G + j;
       if (t < NT) {
-        facc acc = tile_mma<V, KS>(st, j, in);
-        if (t > 0) { epi(t - 1, prev); interleave_mfma_valu<KS>(); }
-        prev = acc;
+        const bool two = AVC_PAIR && (j + 1 < G) && (t + 1 < NT);
+        facc a0, a1;
+        if (two) tile_mma_pair<V, KS>(st, j, in, a0, a1);
+        else a0 = tile_mma<V, KS>(st, j, in);
+        if (np > 0) {
+          epi(tp, prev0);
+          if (np > 1) epi(tp + 1, prev1);
+          if (two) { interleave_mfma_valu<KS>(); interleave_mfma_valu<KS>(); } else interleave_mfma_valu<KS>();
+        }
+        prev0 = a0;
+        if (two) prev1 = a1;
+        tp = t; np = two ? 2 : 1;
         __builtin_amdgcn_sched_barrier(0);   // keep epilogues from being sunk past later tiles
       }
     }
     st.par ^= 1;
   }
-  epi(NT - 1, prev);
+  epi(tp, prev0);
+  if (np > 1) epi(tp + 1, prev1);
   __builtin_amdgcn_sched_barrier(0);
 }
 // ---- the same layer with the epilogue's global loads issued BEFORE the MFMA chain they trail: pre(t) returns the raw loads

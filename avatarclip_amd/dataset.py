@@ -79,6 +79,20 @@ class SMPL_Dataset:
         """dataset.py:295-312."""
         return self.gen_rays_pose(self.poses[img_idx], resolution_level)
 
+    def gen_rays_between(self, idx_0, idx_1, ratio, resolution_level=1):
+        """dataset.py:132-162 (defined on the reference's base Dataset; its SMPL_Dataset lacks the intrinsics it reads, so
+        `render_novel_image` only runs there for the base class): rotation slerp + linear translation between the two
+        world-to-camera matrices, rays through this dataset's pinhole camera."""
+        from scipy.spatial.transform import Rotation as Rot, Slerp
+        w0 = np.linalg.inv(self.poses[idx_0].detach().cpu().numpy().astype(np.float64))
+        w1 = np.linalg.inv(self.poses[idx_1].detach().cpu().numpy().astype(np.float64))
+        rot = Slerp([0, 1], Rot.from_matrix(np.stack([w0[:3, :3], w1[:3, :3]])))(ratio)
+        pose = np.diag([1.0, 1.0, 1.0, 1.0])
+        pose[:3, :3] = rot.as_matrix()
+        pose[:3, 3] = ((1.0 - ratio) * w0 + ratio * w1)[:3, 3]
+        pose = np.linalg.inv(pose).astype(np.float32)
+        return self.gen_rays_pose(torch.from_numpy(pose), resolution_level)
+
     def gen_random_rays_at(self, img_idx, batch_size):
         """dataset.py:314-329 -> [B,10] = o, d, rgb, mask."""
         px = torch.randint(low=0, high=self.W, size=[batch_size])

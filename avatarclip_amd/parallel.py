@@ -37,9 +37,49 @@ def broadcast_params(params, src=0):
         dist.broadcast(p.data, src=src)
 
 
+def broadcast_tensor(t, src=0):
+    if dist.is_available() and dist.is_initialized():
+        dist.broadcast(t, src=src)
+    return t
+
+
+class GradBucket:
+    """One persistent flat fp32 buffer that backs the .grad of every trainable tensor (a single
+    bucket of 400 065 floats = 1.6 MB for the full nets).  The gradients are views into the bucket, so the per-step
+    collective is exactly one all-reduce on memory autograd already wrote -- no per-step cat / copy-back of 28 tensors.
+    A parameter that received no gradient this step contributes zeros (identical layout on every rank)."""
+
+    def __init__(self, params):
+        self.params = list(params)
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(n, dtype=self.params[0].dtype, device=self.params[0].device)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.attach()
+
+    def attach(self):
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def allreduce_mean(self):
+        world = rank_world()[1]
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            if g is None:            # optimizer.zero_grad(set_to_none=True) and no gradient this step
+                v.zero_()
+            elif g.data_ptr() != v.data_ptr():   # autograd replaced the tensor: bring it home (first step only)
+                v.copy_(g)
+            p.grad = v
+        if world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(world)
+
+
 def allreduce_grads(params, world=None):
-    """Average the gradients of `params` over all ranks with one flat bucket.  Parameters whose grad is None on this
-    rank contribute zeros (the bucket layout must be identical on every rank)."""
+    """Average the gradients of `params` over all ranks (stateless form: one temporary flat bucket; Runner keeps a
+    persistent GradBucket instead)."""
     if world is None:
         world = rank_world()[1]
     if world <= 1:

@@ -5,14 +5,18 @@ Differences that are deliberate and documented:
   * view-sharded data parallelism (not in the reference, which is single-GPU): when torch.distributed is
     initialised every rank draws its own camera and ONE flat-bucket all-reduce (RCCL over xGMI) averages the
     gradients before the identical Adam step (SURVEY.md §8e);
-  * the SMPL silhouette prior (smplx + neural_renderer, main.py:290-335,360) and the CLIP text tower are outside
-    the hot path: `init_smpl(prior_renderer=...)` / `init_clip(perceptor=..., text_embeddings=...)` take them as
-    inputs; procedural / seeded stand-ins are used (with a warning) when they are not supplied;
+  * the SMPL silhouette prior (smplx + neural_renderer, main.py:290-335,360) is rendered by the HIP rasteriser of
+    smpl_prior.py from a posed mesh (`general.smpl_mesh`, an .obj, or `init_smpl(prior_renderer=...)`); the licensed SMPL
+    pickles stay an input.  Seeded CLIP weights, seeded text embeddings, the procedural ellipsoid prior and a missing
+    `train.pretrain` are STAND-INS for benchmarks and tests: they must be asked for (`allow_standins=True` /
+    `general.allow_standins = True`), otherwise the Runner raises instead of training on meaningless inputs;
   * tensorboard logging is optional (absent offline) and scalar logging does not force a device sync every step.
 """
+import importlib
 import logging
 import os
 import random
+import types
 from shutil import copyfile
 
 import numpy as np
@@ -58,7 +62,7 @@ class EllipsoidPrior:
 
 class Runner:
     def __init__(self, conf_path, mode="train", case="CASE_NAME", is_continue=False, is_colab=False, conf=None,
-                 device=None, data_root=None):
+                 device=None, data_root=None, allow_standins=None):
         if device is None:
             if not torch.cuda.is_available():
                 raise RuntimeError("avatarclip_amd.Runner needs an MI355X (torch.cuda) -- the hot path has no CPU fallback")
@@ -71,6 +75,8 @@ class Runner:
             with open(self.conf_path) as f:
                 self.conf = ConfigFactory.parse_string(f.read())
         self.rank, self.world = parallel.rank_world()
+        self.allow_standins = bool(self.conf.get_bool("general.allow_standins", default=False)
+                                   if allow_standins is None else allow_standins)
         self.base_exp_dir = self.conf["general.base_exp_dir"]
         os.makedirs(self.base_exp_dir, exist_ok=True)
         ds_conf = self.conf.get("dataset", default=None)
@@ -109,8 +115,8 @@ class Runner:
         self.use_bg_aug = c.get_bool("train.use_bg_aug", default=True)
         self.full_frame_resolution_level = c.get_float("train.full_frame_resolution_level", default=2.25)  # main.py:371
         seed = c.get_int("train.seed", default=None)
+        self.seed = seed
         if seed is not None:
-            self.seed = seed
             torch.manual_seed(seed); torch.cuda.manual_seed_all(seed); random.seed(seed); np.random.seed(seed)
         self.smpl_model_path = c.get_string("general.smpl_model_path", default="../../smpl_models")
         self.pose_type = c.get_string("general.pose_type", default="stand_pose")
@@ -129,6 +135,8 @@ class Runner:
         self.params_to_train = params_to_train
         if self.world > 1:
             parallel.broadcast_params(params_to_train)
+            self.seed_data_rngs()
+        self.grad_bucket = parallel.GradBucket(params_to_train) if self.world > 1 else None
         self.optimizer = torch.optim.Adam(params_to_train, lr=self.learning_rate)
         self.renderer = NeuSRenderer(self.nerf_outside, self.sdf_network, self.deviation_network, self.color_network,
                                      **self.conf["model.neus_renderer"])
@@ -137,8 +145,12 @@ class Runner:
             if os.path.exists(pretrain_pth):
                 logging.info("Load pretrain: {}".format(pretrain_pth))
                 self.load_pretrain(pretrain_pth)
+            elif self.allow_standins:
+                logging.warning("pretrain %s not found -- starting from the geometric initialisation (stand-in)", pretrain_pth)
             else:
-                logging.warning("pretrain %s not found -- starting from the geometric initialisation", pretrain_pth)
+                raise FileNotFoundError("train.pretrain = %s does not exist (the reference fails here too, main.py:153-155); "
+                                        "set general.allow_standins = True to start from the geometric initialisation"
+                                        % pretrain_pth)
         latest_model_name = None
         if is_continue:
             model_list = [m for m in os.listdir(os.path.join(self.base_exp_dir, "checkpoints"))
@@ -153,6 +165,36 @@ class Runner:
         self.perceptor = None
         self.prior_renderer = None
 
+    def seed_data_rngs(self):
+        """View-sharded data parallelism: the weights are identical on every rank (broadcast), the DATA must not be.  The
+        reference seeds numpy / random / torch once (main.py:104-116); with that alone every rank would draw the same
+        cameras, backgrounds, lights, image permutations, pixels and z-jitter and the all-reduce would average N identical
+        gradients.  Rank r > 0 re-seeds its data RNGs with seed + r (rank 0 keeps the single-GPU stream); without
+        train.seed a base seed is drawn on rank 0 and broadcast."""
+        base = self.seed
+        if base is None:
+            t = torch.tensor([int(np.random.randint(0, 2 ** 31 - 1))], dtype=torch.int64, device=self.device)
+            parallel.broadcast_tensor(t)
+            base = int(t.item())
+        self.data_seed = base + self.rank
+        if self.rank > 0 or self.seed is None:
+            np.random.seed(self.data_seed); random.seed(self.data_seed)
+            torch.manual_seed(self.data_seed)
+            if self.device.type == "cuda":
+                torch.cuda.manual_seed(self.data_seed)
+
+    def _validation_hooks(self, clip_stage):
+        """main.py:247-251 / 556-561: periodic images and meshes (rank 0)."""
+        if self.rank != 0:
+            return
+        if self.val_freq > 0 and self.iter_step % self.val_freq == 0:
+            if clip_stage:
+                self.validate_image(idx=58 if self.dataset.n_images > 58 else -1, save=True)
+            else:
+                self.validate_image(save=True)
+        if self.val_mesh_freq > 0 and self.iter_step % self.val_mesh_freq == 0:
+            self.validate_mesh()
+
     # ------------------------------------------------------------------ NeuS-init stage (main.py:180-256)
     def train(self):
         self.update_learning_rate()
@@ -165,6 +207,7 @@ class Runner:
                 print("iter:{:8>d} loss = {} lr={}".format(self.iter_step, loss.item(), self.optimizer.param_groups[0]["lr"]))
             if self.iter_step % self.save_freq == 0 and self.rank == 0:
                 self.save_checkpoint()
+            self._validation_hooks(clip_stage=False)
             self.update_learning_rate()
             if self.iter_step % len(image_perm) == 0:
                 image_perm = self.get_image_perm()
@@ -181,24 +224,30 @@ class Runner:
         color_fine_loss = F.l1_loss(color_error, torch.zeros_like(color_error), reduction="sum") / mask_sum
         mask_loss = F.binary_cross_entropy(render_out["weight_sum"].clip(1e-3, 1.0 - 1e-3), mask)
         loss = color_fine_loss + render_out["gradient_error"] * self.igr_weight + mask_loss * self.mask_weight
-        self.optimizer.zero_grad()
+        self.optimizer.zero_grad(set_to_none=self.grad_bucket is None)
         loss.backward()
-        parallel.allreduce_grads(self.params_to_train, self.world)
+        if self.grad_bucket is not None:
+            self.grad_bucket.allreduce_mean()
         self.optimizer.step()
         self.iter_step += 1
         return loss.detach()
 
     # ------------------------------------------------------------------ CLIP stage set-up (main.py:258-335)
+    def _standin(self, what):
+        if not self.allow_standins:
+            raise RuntimeError("%s is missing and stand-ins are not allowed for this run (pass allow_standins=True or set "
+                               "general.allow_standins = True for benchmarks / tests)" % what)
+        logging.warning("%s is missing: using the seeded / procedural stand-in", what)
+
     def init_clip(self, perceptor=None, text_embeddings=None, clip_state_dict=None):
         from . import clip_vit
         if perceptor is None:
             if clip_state_dict is None:
-                path = self.conf.get_string("clip.weights", default=None)
+                path = self.conf.get_string("clip.weights", default=None) or os.environ.get("AVC_CLIP_WEIGHTS")
                 if path is not None and os.path.exists(path):
-                    obj = torch.jit.load(path, map_location="cpu") if path.endswith(".pt") else torch.load(path, map_location="cpu")
-                    clip_state_dict = obj.state_dict() if hasattr(obj, "state_dict") else obj
+                    clip_state_dict = clip_vit.load_state_dict(path)
                 else:
-                    logging.warning("no CLIP ViT-B/32 weights supplied (clip.weights): using seeded random weights")
+                    self._standin("the CLIP ViT-B/32 state dict (clip.weights / $AVC_CLIP_WEIGHTS)")
                     clip_state_dict = clip_vit_random_state_dict(0)
             perceptor = clip_vit.ClipVisionB32(clip_state_dict, self.device)
         self.perceptor = perceptor
@@ -222,8 +271,7 @@ class Runner:
                 from .tokenizer import tokenize
                 print("%s: %s" % (key, text))
                 return self.perceptor.encode_text(tokenize([text], tokenizer)).detach()
-            logging.warning("no text embedding for clip.%s (needs full CLIP weights + the BPE table, or text_embeddings=): "
-                            "using a seeded random unit vector", key)
+            self._standin("the text embedding of clip.%s (needs the full CLIP weights + the BPE table, or text_embeddings=)" % key)
             g = torch.Generator().manual_seed(seed)
             v = torch.randn(1, 512, generator=g)
             return (v / v.norm()).to(self.device)
@@ -234,9 +282,22 @@ class Runner:
             self.encoded_back_text = emb("back_prompt", 13)
 
     def init_smpl(self, prior_renderer=None):
+        """main.py:290-335: the posed SMPL body whose renders supervise colour and mask.  `prior_renderer(eye, at)` returns
+        the [256,256,3] render of `render_one_batch` (models/utils.py:108-125).  Sources, in order: the argument; the conf
+        key `general.smpl_prior = module:callable` (called with this Runner); `general.smpl_mesh = <posed mesh .obj>`
+        rendered by the HIP rasteriser (smpl_prior.MeshPrior); else the procedural ellipsoid -- a stand-in."""
         if prior_renderer is None:
-            logging.warning("no SMPL prior renderer supplied: using the procedural ellipsoid prior")
-            prior_renderer = EllipsoidPrior(device=self.device)
+            spec = self.conf.get_string("general.smpl_prior", default=None)
+            mesh_path = self.conf.get_string("general.smpl_mesh", default=None)
+            if spec is not None:
+                mod, fn = spec.split(":")
+                prior_renderer = getattr(importlib.import_module(mod), fn)(self)
+            elif mesh_path is not None:
+                from . import smpl_prior
+                prior_renderer = smpl_prior.MeshPrior.from_obj(mesh_path, device=self.device)
+            else:
+                self._standin("the SMPL prior (general.smpl_mesh / general.smpl_prior / init_smpl(prior_renderer=...))")
+                prior_renderer = EllipsoidPrior(device=self.device)
         self.prior_renderer = prior_renderer
 
     # ------------------------------------------------------------------ CLIP-guided loop (main.py:337-566)
@@ -252,6 +313,7 @@ class Runner:
                 print("iter:{:8>d} loss = {} lr={}".format(self.iter_step, loss.item(), self.optimizer.param_groups[0]["lr"]))
             if self.iter_step % self.save_freq == 0 and self.rank == 0:
                 self.save_checkpoint()
+            self._validation_hooks(clip_stage=True)
             self.update_learning_rate()
 
     def sample_camera(self, iter_i):
@@ -265,7 +327,11 @@ class Runner:
         eye = eye.astype(np.float32) + at
         return eye, at, theta, phi, is_front
 
-    def train_clip_iteration(self, iter_i, camera=None):
+    # The iteration is split into the stages of main.py so that each stage can be driven with injected inputs by the parity
+    # tests (tests/test_glue_golden.py runs the glue on fixtures produced by the reference's own lines):
+    #   make_view (main.py:348-385) -> draw_background (:387-415) -> renderer.render (:417-420)
+    #   -> shade_and_scatter (:422-487) -> assemble_loss (:489-534) -> backward / all-reduce / Adam (:536-538)
+    def make_view(self, iter_i, camera=None):
         dev = self.device
         eye, at, theta, phi, is_front = camera if camera is not None else self.sample_camera(iter_i)
         pose = torch.from_numpy(lookat(eye, at, np.array([0, 1, 0]))).float().to(dev)
@@ -286,43 +352,52 @@ class Runner:
             .squeeze(0).permute(1, 2, 0).reshape(-1, 3)                                        # main.py:376-377 (nearest)
         mask = (true_rgb != 0).float()[..., :1]
         near, far = self.dataset.near_far_from_sphere(rays_o, rays_d)
-        # background augmentation (main.py:387-405)
+        return types.SimpleNamespace(eye=eye, at=at, theta=theta, phi=phi, is_front=is_front, pose=pose, H=H, W=W,
+                                     rays_o=rays_o, rays_d=rays_d, near=near, far=far, true_rgb=true_rgb, mask=mask,
+                                     dilated_mask=dilated_mask)
+
+    def draw_background(self, view, choice_i=None):
+        """main.py:387-415 -> (choice_i, background_rgb [1,3] | [H*W,1] | None, what render() gets)."""
+        dev, H, W = self.device, view.H, view.W
         background_rgb = None
-        choice_i = np.random.choice(4) if self.use_bg_aug else 3
+        if choice_i is None:
+            choice_i = np.random.choice(4) if self.use_bg_aug else 3
         if choice_i == 0:
             background_rgb = torch.ones([1, 3], device=dev)
         elif choice_i == 1:
             gaussian = torch.normal(torch.zeros([H, W, 1], device=dev) + 0.5, torch.zeros([H, W, 1], device=dev) + 0.2)
             background_rgb = torch.clamp(gaussian, min=0, max=1).reshape(-1, 1)
         elif choice_i == 2:
-            chess_board = torch.zeros([H, W, 1], device=dev) + 0.2
             chess_length = H // np.random.choice(np.arange(10, 20))
-            ii = torch.arange(H, device=dev)[:, None] // chess_length
-            jj = torch.arange(W, device=dev)[None, :] // chess_length
-            chess_board[((ii + jj) % 2 == 0)] = 0.8
-            sigma = float(np.random.uniform(0.1, 2.0))     # torchvision GaussianBlur(kernel (5,9), sigma U(0.1,2))
-            background_rgb = _gaussian_blur(chess_board.permute(2, 0, 1).unsqueeze(0), (5, 9), sigma) \
-                .squeeze(0).permute(1, 2, 0).reshape(-1, 1)
-        mask = (mask > 0.5).float() if self.mask_weight > 0.0 else torch.ones_like(mask)
+            sigma = torch.empty(1).uniform_(0.1, 2.0).item()   # torchvision GaussianBlur.get_params: torch CPU RNG
+            background_rgb = chess_background(H, W, chess_length, sigma, dev)
         if self.use_silhouettes and choice_i in (1, 2):
-            masked_background_rgb = background_rgb.reshape(H, W, 1)[dilated_mask].reshape(-1, 1)
+            masked_background_rgb = background_rgb.reshape(H, W, 1)[view.dilated_mask].reshape(-1, 1)
         else:
             masked_background_rgb = background_rgb
-        mask_sum = mask.sum() + 1e-5
-        render_out = self.renderer.render(rays_o, rays_d, near, far, background_rgb=masked_background_rgb,
-                                          cos_anneal_ratio=self.get_cos_anneal_ratio())
+        return choice_i, background_rgb, masked_background_rgb
+
+    def shade_and_scatter(self, render_out, view, choice_i, background_rgb, light=None):
+        """main.py:422-487: Lambert shading from the rendered normals (random light around the camera, random ambience),
+        then -- in silhouette mode -- the masked rays are scattered back into full images over the augmentation background.
+        `light` = (light_dir[3], ambience) injects the numpy draws (tests)."""
+        dev, H, W = self.device, view.H, view.W
         color_fine = render_out["color_fine"]
         extra_color_fine = render_out["extra_color_fine"]
-        # cast light (main.py:426-453)
+        texture_shading = rand_shading_rgb = None
         if self.add_no_texture or self.texture_cast_light:
             normals = (render_out["gradients"] * render_out["weights"][:, :, None]).sum(dim=1)
             normals = normals / (torch.norm(normals, dim=-1, keepdim=True) + 1e-7)
-            light_dir = sphere_coord(theta + np.random.uniform(-np.pi / 4, np.pi / 4), phi + np.random.uniform(-np.pi / 4, np.pi / 4))
-            rand_light_d = torch.zeros_like(normals) + torch.from_numpy(light_dir).float().to(dev)
+            if light is None:
+                light_dir = sphere_coord(view.theta + np.random.uniform(-np.pi / 4, np.pi / 4),
+                                         view.phi + np.random.uniform(-np.pi / 4, np.pi / 4))
+            else:
+                light_dir = np.asarray(light[0])
+            rand_light_d = torch.zeros_like(normals) + torch.from_numpy(np.asarray(light_dir)).float().to(dev)
             rand_light_d = rand_light_d / (torch.norm(rand_light_d, dim=-1, keepdim=True) + 1e-7)
             rand_diffuse_shading = (normals * rand_light_d).sum(-1, keepdim=True).clamp(min=0, max=1)
             rand_diffuse_shading = torch.where(torch.isnan(rand_diffuse_shading), torch.ones_like(rand_diffuse_shading), rand_diffuse_shading)
-            ambience = np.random.uniform(0, 0.2)
+            ambience = np.random.uniform(0, 0.2) if light is None else float(light[1])
             rand_shading = ambience + (1 - ambience) * rand_diffuse_shading
             ws = render_out["weight_sum"].reshape(-1)
             bgm = (ws < 0.5)[:, None]
@@ -331,6 +406,7 @@ class Runner:
             texture_shading = (extra_color_fine * rand_shading).clamp(min=0, max=1)
         weight_sum = render_out["weight_sum"]
         if self.use_silhouettes:  # scatter the masked rays back to full images (main.py:461-487)
+            dilated_mask = view.dilated_mask
             background = torch.zeros([H, W, 3], device=dev)
             if choice_i == 0:
                 background[:] = 1
@@ -347,38 +423,56 @@ class Runner:
             extra_color_fine = scatter(extra_color_fine, background)
             color_fine = scatter(color_fine, torch.zeros([H, W, 3], device=dev))
             weight_sum = scatter(weight_sum, torch.zeros([H, W, 1], device=dev))
-        # losses (main.py:489-534)
-        color_error = (color_fine - true_rgb) * mask
+        return dict(color_fine=color_fine, extra_color_fine=extra_color_fine, weight_sum=weight_sum,
+                    texture_shading=texture_shading, rand_shading_rgb=rand_shading_rgb)
+
+    def assemble_loss(self, render_out, comp, view, iter_i):
+        """main.py:489-534."""
+        H, W = view.H, view.W
+        mask = (view.mask > 0.5).float() if self.mask_weight > 0.0 else torch.ones_like(view.mask)
+        mask_sum = mask.sum() + 1e-5
+        color_error = (comp["color_fine"] - view.true_rgb) * mask
         color_fine_loss = F.l1_loss(color_error, torch.zeros_like(color_error), reduction="sum") / mask_sum
         eikonal_loss = render_out["gradient_error"]
-        mask_loss = F.binary_cross_entropy(weight_sum.clip(1e-3, 1.0 - 1e-3), mask)
+        mask_loss = F.binary_cross_entropy(comp["weight_sum"].clip(1e-3, 1.0 - 1e-3), mask)
         if self.use_face_prompt and iter_i % 4 == 0:
             text = self.encoded_face_text
-        elif self.use_back_prompt and is_front == 0:
+        elif self.use_back_prompt and view.is_front == 0:
             text = self.encoded_back_text
         else:
             text = self.encoded_text
-        img = texture_shading if self.texture_cast_light else extra_color_fine
+        img = comp["texture_shading"] if self.texture_cast_light else comp["extra_color_fine"]
         if self.add_no_texture:
             # main.py:512 and :524 encode the two images in two calls; the encoder treats batch entries independently, so
             # one B=2 pass gives the same two embeddings with every frozen ViT weight streamed once instead of twice
             enc_both = self.perceptor.encode_image(torch.cat([self.clip_preprocess(img.reshape(H, W, 3)),
-                                                              self.clip_preprocess(rand_shading_rgb.reshape(H, W, 3))], dim=0))
+                                                              self.clip_preprocess(comp["rand_shading_rgb"].reshape(H, W, 3))], dim=0))
             enc, enc2 = enc_both[0:1], enc_both[1:2]
         else:
             enc = self.perceptor.encode_image(self.clip_preprocess(img.reshape(H, W, 3)))
         cosine = torch.cosine_similarity(torch.mean(enc, dim=0), torch.mean(text, dim=0), dim=0)
         loss = color_fine_loss + eikonal_loss * self.igr_weight + mask_loss * self.mask_weight + (1.0 - cosine) * self.clip_weight
+        cosine_shading = None
         if self.add_no_texture:
             cosine_shading = torch.cosine_similarity(torch.mean(enc2, dim=0), torch.mean(text, dim=0), dim=0)
             loss = loss + (1.0 - cosine_shading) * self.clip_weight
-        self.optimizer.zero_grad()
+        return loss, dict(color=color_fine_loss, eikonal=eikonal_loss, mask=mask_loss, cosine=cosine, cosine_shading=cosine_shading)
+
+    def train_clip_iteration(self, iter_i, camera=None):
+        view = self.make_view(iter_i, camera)
+        choice_i, background_rgb, masked_background_rgb = self.draw_background(view)
+        render_out = self.renderer.render(view.rays_o, view.rays_d, view.near, view.far, background_rgb=masked_background_rgb,
+                                          cos_anneal_ratio=self.get_cos_anneal_ratio())
+        comp = self.shade_and_scatter(render_out, view, choice_i, background_rgb)
+        loss, parts = self.assemble_loss(render_out, comp, view, iter_i)
+        self.optimizer.zero_grad(set_to_none=self.grad_bucket is None)
         loss.backward()
-        parallel.allreduce_grads(self.params_to_train, self.world)     # one RCCL all-reduce per step (K17)
+        if self.grad_bucket is not None:
+            self.grad_bucket.allreduce_mean()     # one RCCL all-reduce per step (K17)
         self.optimizer.step()
         self.iter_step += 1
-        self.last_stats = dict(loss=loss.detach(), color=color_fine_loss.detach(), eikonal=eikonal_loss.detach(),
-                               cosine=cosine.detach(), rays=rays_o.shape[0])
+        self.last_stats = dict(loss=loss.detach(), color=parts["color"].detach(), eikonal=parts["eikonal"].detach(),
+                               cosine=parts["cosine"].detach(), rays=view.rays_o.shape[0])
         return loss.detach()
 
     # ------------------------------------------------------------------ schedule / checkpoints (main.py:568-632)
@@ -439,28 +533,114 @@ class Runner:
         os.makedirs(os.path.join(self.base_exp_dir, "checkpoints"), exist_ok=True)
         torch.save(checkpoint, os.path.join(self.base_exp_dir, "checkpoints", "ckpt_{:0>6d}.pth".format(self.iter_step)))
 
-    @torch.no_grad()
-    def validate_image(self, idx=-1, resolution_level=-1, pose=None):
-        """Renders one view in chunks of `batch_size` rays (main.py:741-820, image assembly only)."""
+    def _render_chunks(self, rays_o, rays_d, keys, chunk=None, **render_kw):
+        """render() over chunks of rays without keeping a graph (main.py:752-783 and its siblings); returns dict of cats."""
+        chunk = chunk or self.batch_size * 16     # the kernels want >= a few thousand rays per launch; the result is chunk-invariant
+        outs = {k: [] for k in keys}
+        bg = torch.ones([1, 3], device=self.device) if self.use_white_bkgd else None
+        for o, d in zip(rays_o.split(chunk), rays_d.split(chunk)):
+            near, far = self.dataset.near_far_from_sphere(o, d)
+            with torch.no_grad():
+                out = self.renderer.render(o.contiguous(), d.contiguous(), near, far, background_rgb=render_kw.get("background_rgb", bg),
+                                           cos_anneal_ratio=self.get_cos_anneal_ratio(),
+                                           perturb_overwrite=render_kw.get("perturb_overwrite", -1))
+            for k in keys:
+                if k == "normals":   # main.py:773-778
+                    n = out["gradients"] * out["weights"][:, :, None]
+                    if render_kw.get("inside_only", True) and out.get("inside_sphere") is not None:
+                        n = n * out["inside_sphere"][..., None]
+                    outs[k].append(n.sum(dim=1))
+                else:
+                    outs[k].append(out[k].detach())
+        return {k: torch.cat(v, 0) for k, v in outs.items()}
+
+    def validate_image(self, idx=-1, resolution_level=-1, pose=None, save=False, perturb_overwrite=-1):
+        """main.py:741-820.  Returns the [H,W,3] image (extra_color when the colour net has the CLIP head); with save=True
+        also writes validations_fine/, validations_extra_fine/ and normals/ PNGs under base_exp_dir with the reference's
+        file names and channel conventions (cv.imwrite takes BGR: the colour and normal images are written un-converted,
+        i.e. channel-swapped on disk, the extra-colour image is converted first -- reproduced literally)."""
         if resolution_level < 0:
             resolution_level = self.validate_resolution_level
         if pose is None:
             if idx < 0:
                 idx = np.random.randint(self.dataset.n_images)
             pose = self.dataset.poses[idx]
+        print("Validate: iter: {}, camera: {}".format(self.iter_step, idx))
         rays_o, rays_d = self.dataset.gen_rays_pose(pose, resolution_level)
         H, W, _ = rays_o.shape
-        ro, rd = rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float()
-        outs = []
-        with torch.enable_grad():
-            for o, d in zip(ro.split(self.batch_size * 16), rd.split(self.batch_size * 16)):
-                near, far = self.dataset.near_far_from_sphere(o, d)
-                bg = torch.ones([1, 3], device=self.device) if self.use_white_bkgd else None
-                out = self.renderer.render(o.contiguous(), d.contiguous(), near, far, perturb_overwrite=0, background_rgb=bg,
-                                           cos_anneal_ratio=self.get_cos_anneal_ratio())
-                outs.append((out["extra_color_fine"] if self.extra_color else out["color_fine"]).detach())
-        return torch.cat(outs, 0).reshape(H, W, 3).clamp(0, 1)
+        keys = ["color_fine", "normals"] + (["extra_color_fine"] if self.extra_color else [])
+        res = self._render_chunks(rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float(), keys, perturb_overwrite=perturb_overwrite)
+        img_fine = (res["color_fine"].reshape(H, W, 3) * 255).clip(0, 255)
+        extra = (res["extra_color_fine"].reshape(H, W, 3) * 255).clip(0, 255) if self.extra_color else None
+        rot = torch.linalg.inv(torch.as_tensor(pose)[:3, :3].to(self.device).float())
+        normal_img = (torch.matmul(rot[None], res["normals"][:, :, None]).reshape(H, W, 3) * 128 + 128).clip(0, 255)
+        self.last_validation = dict(color=img_fine, extra=extra, normal=normal_img)
+        if save:
+            from PIL import Image
+            tag = "{:0>8d}_{}_{}.png".format(self.iter_step, 0, idx)
+            u8 = lambda t: np.ascontiguousarray(t.detach().cpu().numpy().astype(np.uint8))
+            for sub in ("validations_fine", "validations_extra_fine", "normals"):
+                os.makedirs(os.path.join(self.base_exp_dir, sub), exist_ok=True)
+            fine = u8(img_fine)
+            if idx >= 0 and self.dataset.images_lis:
+                fine = np.concatenate([fine, self.dataset.image_at(idx, resolution_level=resolution_level)])
+            Image.fromarray(np.ascontiguousarray(fine[..., ::-1])).save(os.path.join(self.base_exp_dir, "validations_fine", tag))
+            if extra is not None:
+                Image.fromarray(u8(extra)).save(os.path.join(self.base_exp_dir, "validations_extra_fine", tag))
+            Image.fromarray(np.ascontiguousarray(u8(normal_img)[..., ::-1])).save(os.path.join(self.base_exp_dir, "normals", tag))
+        return ((extra if extra is not None else img_fine) / 255.0).clamp(0, 1)
 
+    def render_novel_image(self, idx_0, idx_1, ratio, resolution_level):
+        """main.py:822-848: the view interpolated between cameras idx_0 and idx_1 -> uint8 [H,W,3] (x256 like the reference)."""
+        rays_o, rays_d = self.dataset.gen_rays_between(idx_0, idx_1, ratio, resolution_level=resolution_level)
+        H, W, _ = rays_o.shape
+        res = self._render_chunks(rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float(), ["color_fine"])
+        return (res["color_fine"].reshape(H, W, 3).cpu().numpy() * 256).clip(0, 255).astype(np.uint8)
+
+    def interpolate_view(self, img_idx_0, img_idx_1, n_frames=60, resolution_level=4):
+        """main.py:921-944: 60 frames forth and back between two cameras.  cv2.VideoWriter is not available offline: the
+        frames are written as an animated GIF (30 fps) plus numbered PNGs under base_exp_dir/render/."""
+        from PIL import Image
+        images = [self.render_novel_image(img_idx_0, img_idx_1, np.sin(((i / n_frames) - 0.5) * np.pi) * 0.5 + 0.5,
+                                          resolution_level=resolution_level) for i in range(n_frames)]
+        images = images + images[::-1]
+        video_dir = os.path.join(self.base_exp_dir, "render")
+        os.makedirs(video_dir, exist_ok=True)
+        stem = os.path.join(video_dir, "{:0>8d}_{}_{}".format(self.iter_step, img_idx_0, img_idx_1))
+        frames = [Image.fromarray(im) for im in images]
+        frames[0].save(stem + ".gif", save_all=True, append_images=frames[1:], duration=33, loop=0)
+        return stem + ".gif"
+
+    def render_geometry_cast_light(self, light=None):
+        """main.py:634-739: 512x512 close-up of the head, textured colour under one random Lambert light (ambience 0, black
+        background) -> base_exp_dir/cast_light_texture_head_black.png."""
+        phi, theta, camera_distance = 0, 0, 0.5
+        eye = np.array([camera_distance * np.sin(theta) * np.cos(phi), camera_distance * np.sin(theta) * np.sin(phi),
+                        camera_distance * np.cos(theta)])
+        at = np.array([0, self.head_height, 0.3])
+        eye = eye + at
+        pose = torch.from_numpy(lookat(eye, at, np.array([0, 1, 0]))).float()
+        rays_o, rays_d = self.dataset.gen_rays_pose(pose, 0.5)
+        H, W = rays_o.shape[0], rays_o.shape[1]
+        if light is None:
+            light = sphere_coord(theta + np.random.uniform(-np.pi / 4, np.pi / 4), phi + np.random.uniform(-np.pi / 4, np.pi / 4))
+        np.random.choice(np.arange(10, 20))      # main.py:676 draws the chess length although choice_i is fixed to 3
+        res = self._render_chunks(rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float(),
+                                  ["extra_color_fine" if self.extra_color else "color_fine", "normals", "weight_sum"],
+                                  background_rgb=None, inside_only=False)
+        extra = res["extra_color_fine" if self.extra_color else "color_fine"]
+        normals = res["normals"] / (torch.norm(res["normals"], dim=-1, keepdim=True) + 1e-7)
+        ld = torch.from_numpy(np.asarray(light)).float().to(self.device)
+        ld = (torch.zeros_like(normals) + ld)
+        ld = ld / (torch.norm(ld, dim=-1, keepdim=True) + 1e-7)
+        shading = (normals * ld).sum(-1, keepdim=True).clamp(min=0, max=1)
+        shading = torch.where(torch.isnan(shading), torch.ones_like(shading), shading)
+        shading = torch.where((res["weight_sum"].reshape(-1) < 0.5)[:, None], torch.ones_like(shading), shading)
+        img = (extra * shading).clamp(0, 1).reshape(H, W, 3)
+        from PIL import Image
+        path = os.path.join(self.base_exp_dir, "cast_light_texture_head_black.png")
+        Image.fromarray((255 * np.clip(img.cpu().numpy(), 0, 1)).astype(np.uint8)).save(path)   # to8b
+        return path
 
     def validate_mesh(self, world_space=False, resolution=256, threshold=0.0):
         """main.py:850-919: marching cubes of -sdf over the dataset bounding box, vertex colours picked from six axis views
@@ -521,6 +701,15 @@ def clip_vit_random_state_dict(seed):
         sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"] = rn(4 * W, W, std=(2 * W) ** -0.5), torch.zeros(4 * W)
         sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"] = rn(W, 4 * W, std=W ** -0.5 * (2 * L) ** -0.5), torch.zeros(W)
     return sd
+
+
+def chess_background(H, W, chess_length, sigma, device):
+    """main.py:398-405: 0.2 / 0.8 chess board of `chess_length`-pixel squares, GaussianBlur(kernel (5,9), sigma) -> [H*W,1]."""
+    chess_board = torch.zeros([H, W, 1], device=device) + 0.2
+    ii = torch.arange(H, device=device)[:, None] // chess_length
+    jj = torch.arange(W, device=device)[None, :] // chess_length
+    chess_board[((ii + jj) % 2 == 0)] = 0.8
+    return _gaussian_blur(chess_board.permute(2, 0, 1).unsqueeze(0), (5, 9), float(sigma)).squeeze(0).permute(1, 2, 0).reshape(-1, 1)
 
 
 def _gaussian_blur(x, ksize, sigma):

@@ -35,7 +35,8 @@ def make_conf(res, spp, small=False):
     H = 128 if small else 256
     text = """
 general { base_exp_dir = /tmp/avc_bench_exp
-          recording = [] }
+          recording = []
+          allow_standins = True }
 dataset { H = %d
           W = %d }
 train {

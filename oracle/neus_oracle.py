@@ -360,6 +360,52 @@ def cast_light(render_out, light_dir: np.ndarray, ambience: float):
     return texture_shading, rand_shading_rgb
 
 
+def scatter_to_image(vals, dilated_mask, background):
+    """main.py:461-487: rays rendered only inside the dilated silhouette go back to their pixels of a full [H,W,C] image
+    (`background` = the augmentation background for the CLIP images, zeros for colour / weight_sum)."""
+    full = background.clone()
+    full[dilated_mask] = vals
+    return full.reshape(-1, vals.shape[-1])
+
+
+def silhouette_background(H, W, choice_i, background_rgb, dilated_mask):
+    """main.py:462-466: the full-image background the masked renders are scattered onto."""
+    background = torch.zeros([H, W, 3])
+    if choice_i == 0:
+        background[:] = 1
+    if choice_i in (1, 2):
+        background[~dilated_mask] = background_rgb.reshape(H, W, 1).repeat(1, 1, 3)[~dilated_mask]
+    return background
+
+
+def random_resized_crop_params(height, width, rng, scale=(1.0, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0)):
+    """torchvision.transforms.RandomResizedCrop.get_params restated (third-party, absent offline; main.py:261 builds it with
+    scale=(1,1)): ten tries of area = H W U(scale), log-uniform aspect ratio, accept when the box fits; else the central crop
+    at the clamped ratio.  With scale=(1,1) on a square image every accepted box and the fallback are the FULL frame
+    (tests/test_glue_golden.py checks it over many draws), so the transform reduces to the resize to 224."""
+    area = height * width
+    log_ratio = (np.log(ratio[0]), np.log(ratio[1]))
+    for _ in range(10):
+        target_area = area * rng.uniform(scale[0], scale[1])
+        aspect_ratio = np.exp(rng.uniform(log_ratio[0], log_ratio[1]))
+        w = int(round(np.sqrt(target_area * aspect_ratio)))
+        h = int(round(np.sqrt(target_area / aspect_ratio)))
+        if 0 < w <= width and 0 < h <= height:
+            i = int(rng.randint(0, height - h + 1))
+            j = int(rng.randint(0, width - w + 1))
+            return i, j, h, w
+    in_ratio = float(width) / float(height)
+    if in_ratio < min(ratio):
+        w = width
+        h = int(round(w / min(ratio)))
+    elif in_ratio > max(ratio):
+        h = height
+        w = int(round(h * max(ratio)))
+    else:
+        w, h = width, height
+    return (height - h) // 2, (width - w) // 2, h, w
+
+
 def neus_losses(render_out, true_rgb, mask, igr_weight, mask_weight):
     """main.py:214-224 / 489-497: masked L1 + eikonal + mask BCE."""
     mask_sum = mask.sum() + 1e-5

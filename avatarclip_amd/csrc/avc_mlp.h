@@ -98,7 +98,7 @@ __device__ __forceinline__ void dephase(const ST& st) {
 #define AVC_EPI(...) [&](int t, const facc& acc) __attribute__((always_inline)) { __VA_ARGS__ }
 
 #ifndef AVC_PAIR
-#define AVC_PAIR 1   // 1: two output tiles per MFMA stream (independent accumulators), 0: one dependent chain per tile
+#define AVC_PAIR 0   // 1: two output tiles per MFMA stream (independent accumulators), 0: one dependent chain per tile
 #endif
 template <typename V, int KS, int NT, class ST, typename Epi>
 __device__ __forceinline__ void layer_s(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&in)[KS],

@@ -458,13 +458,19 @@ class Runner:
             loss = loss + (1.0 - cosine_shading) * self.clip_weight
         return loss, dict(color=color_fine_loss, eikonal=eikonal_loss, mask=mask_loss, cosine=cosine, cosine_shading=cosine_shading)
 
-    def train_clip_iteration(self, iter_i, camera=None):
+    def clip_loss(self, iter_i, camera=None):
+        """main.py:348-534: one view from camera to scalar loss (differentiable)."""
         view = self.make_view(iter_i, camera)
         choice_i, background_rgb, masked_background_rgb = self.draw_background(view)
         render_out = self.renderer.render(view.rays_o, view.rays_d, view.near, view.far, background_rgb=masked_background_rgb,
                                           cos_anneal_ratio=self.get_cos_anneal_ratio())
         comp = self.shade_and_scatter(render_out, view, choice_i, background_rgb)
         loss, parts = self.assemble_loss(render_out, comp, view, iter_i)
+        self.last_view = view
+        return loss, parts
+
+    def train_clip_iteration(self, iter_i, camera=None):
+        loss, parts = self.clip_loss(iter_i, camera)
         self.optimizer.zero_grad(set_to_none=self.grad_bucket is None)
         loss.backward()
         if self.grad_bucket is not None:
@@ -472,7 +478,7 @@ class Runner:
         self.optimizer.step()
         self.iter_step += 1
         self.last_stats = dict(loss=loss.detach(), color=parts["color"].detach(), eikonal=parts["eikonal"].detach(),
-                               cosine=parts["cosine"].detach(), rays=view.rays_o.shape[0])
+                               cosine=parts["cosine"].detach(), rays=self.last_view.rays_o.shape[0])
         return loss.detach()
 
     # ------------------------------------------------------------------ schedule / checkpoints (main.py:568-632)

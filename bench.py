@@ -61,6 +61,7 @@ train {
     use_back_prompt = True
     use_silhouettes = False
     full_frame_resolution_level = 1
+    seed = 0
 }
 clip { prompt = a 3D rendering of the Iron Man in unreal engine }
 model {
@@ -154,17 +155,33 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks here (one process per GPU, RCCL over xGMI), exactly the way
+        # the driver would (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+        have = torch.cuda.device_count()
+        if have < args.gpus and not os.environ.get("AVC_SINGLE_DEVICE"):
+            sys.exit("bench.py: --gpus %d requested but only %d device(s) are visible (set AVC_SINGLE_DEVICE=1 AVC_DIST_BACKEND=gloo "
+                     "to exercise the multi-rank path on one GPU)" % (args.gpus, have))
+        import socket
+        import subprocess
+        sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
+
     from avatarclip_amd import parallel
     from avatarclip_amd.engine import Engine
     from avatarclip_amd.runner import Runner
     rank, world, local_rank = parallel.init_from_env()
-    assert world == max(args.gpus, 1) or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    if world != max(args.gpus, 1):
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE = %d (launch with torch.distributed.run --nproc-per-node == --gpus)" % (args.gpus, world))
     if os.environ.get("AVC_SINGLE_DEVICE"):      # development aid: all ranks on device 0 (see parallel.init_from_env)
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    torch.manual_seed(0)             # identical initial weights on every rank
-    np.random.seed(1234 + rank)      # a different camera view per rank (view-sharded DP)
+    # identical initial weights on every rank (train.seed = 0 in the conf + broadcast); the Runner then re-seeds the DATA RNGs
+    # per rank (a different camera view, jitter and light per rank: view-sharded DP, Runner.seed_data_rngs)
     conf = make_conf(args.res, args.spp, args.small)
     runner = Runner(None, mode="train_clip", conf=conf, device=dev)
     runner.init_clip()

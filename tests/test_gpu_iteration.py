@@ -1,13 +1,16 @@
-"""Whole-iteration parity: Runner.train_clip_iteration (main.py:345-566) on the HIP path vs the SAME host glue driving the
-CPU oracle (oracle/neus_oracle.render + oracle/clip_vit_oracle.encode_image) with identical seeds, cameras, jitter and
-weights.  Covers rows a1-a18 of SURVEY section 8 in one pass: rays, hierarchical sampling, the MLPs, compositing,
-shading, CLIP, losses, backward, Adam.  BASELINE config 1 geometry (64 x 64 rays would be the CPU-runnable case; 32 x 32
-rays x 32 spp here keeps the CPU leg at a few seconds), small nets (confs/examples_small).
+"""Whole-iteration parity: Runner.train_clip_iteration (main.py:345-566) on the HIP path vs ONE INDEPENDENT iteration built
+from the CPU oracle only (oracle/iteration_oracle.py: oracle render + cast_light + scatter + losses + clip_preprocess + ViT
+oracle + Adam; it imports nothing of the product's Runner / renderer / engine), with identical weights, cameras, jitter,
+backgrounds, lights and ambience.  Covers rows a1-a18 of SURVEY section 8 in one pass.
 
-Tolerances: per-iteration loss within 2e-3 (the loss is O(1): L1 + eikonal + BCE + 2 x (1 - cos)); per-tensor gradient of
-the first iteration: relative L2 <= 5e-2 (against max(own norm, 1e-4 of the whole gradient)) and cosine >= 0.995 (bf16
-gradient operands; includes the CLIP backward to pixels); the scalar d loss / d (sdf bias) is ill-conditioned and has its
-own 10 % bound (see the comment in the test).
+  * small nets (confs/examples_small), 32 x 32 rays x 32 spp, 2 iterations (the second one after an Adam step);
+  * FULL-SIZE nets (confs/examples), 64 x 64 rays x 64 spp = BASELINE config 1's geometry, 1 iteration (CPU leg ~10 s);
+  * silhouette-ray mode with a gaussian background (ragged ray set + scatter), small nets.
+
+Tolerances (f16 forward / bf16 gradient operands against the fp32 oracle; measured values in DESIGN.md section 2):
+per-iteration loss within 2e-3 (the loss is O(1)); per-tensor gradient: relative L2 <= 2e-2 against max(own norm, 1e-4 of
+the whole gradient) and cosine >= 0.999; the scalar d loss / d (sdf bias) is a sum with heavy cancellation and has its own
+5 % bound; rendered CLIP image max |diff| <= 5e-3.
 """
 import os
 
@@ -18,79 +21,29 @@ import torch
 gpu = pytest.mark.gpu
 
 
-def _make_runner(device, res, spp):
+def _make_runner(device, res, spp, small=True, **over):
     import bench
     from avatarclip_amd.runner import Runner
-    conf = bench.make_conf(res, spp, small=True)
+    conf = bench.make_conf(res, spp, small=small)
     conf.put("train.use_bg_aug", False)
     conf.put("train.warm_up_end", 0)
+    for k, v in over.items():
+        conf.put(k, v)
     torch.manual_seed(0)
     r = Runner(None, mode="train_clip", conf=conf, device=device)
     return r
 
 
-@gpu
-def test_train_clip_iteration_matches_oracle_driven_iteration():
-    from oracle import clip_vit_oracle as C
-    from oracle import neus_oracle as O
-    from avatarclip_amd.runner import clip_vit_random_state_dict, EllipsoidPrior
-    res, spp, iters = 32, 32, 2
-    clip_sd = clip_vit_random_state_dict(0)
-    jit = [torch.rand(res * res, 1, generator=torch.Generator().manual_seed(100 + i)) for i in range(iters)]
+def _oracle_conf(r, res):
+    return dict(H=res, W=res, focal=r.dataset.focal, n_samples=r.renderer.n_samples, n_importance=r.renderer.n_importance,
+                up_sample_steps=r.renderer.up_sample_steps, full_frame_resolution_level=r.full_frame_resolution_level,
+                mask_weight=r.mask_weight, igr_weight=r.igr_weight, clip_weight=r.clip_weight, add_no_texture=r.add_no_texture,
+                texture_cast_light=r.texture_cast_light, use_face_prompt=r.use_face_prompt, use_back_prompt=r.use_back_prompt,
+                use_silhouettes=r.use_silhouettes, cos_anneal_ratio=r.get_cos_anneal_ratio(), extra_color=True)
 
-    # ---------------- product path
-    dev = torch.device("cuda")
-    a = _make_runner(dev, res, spp)
-    a.init_clip(clip_state_dict=clip_sd)
-    a.init_smpl()
-    a.update_learning_rate()
-    step = {"i": 0}
-    a_render = a.renderer.render
-    a.renderer.render = lambda *args, **kw: a_render(*args, jitter=jit[step["i"]].to(dev), **kw)
 
-    # ---------------- the same glue on the CPU, driving the oracle
-    cpu = torch.device("cpu")
-    b = _make_runner(cpu, res, spp)
-
-    class OraclePerceptor:
-        def encode_image(self, x):
-            return C.encode_image(clip_sd, x)
-
-    b.init_clip(perceptor=OraclePerceptor())
-    b.init_smpl(EllipsoidPrior(device=cpu))
-    b.update_learning_rate()
-
-    def oracle_render(rays_o, rays_d, near, far, perturb_overwrite=-1, background_rgb=None, cos_anneal_ratio=0.0):
-        sd_s = dict(b.sdf_network.named_parameters())
-        sd_c = dict(b.color_network.named_parameters())
-        out = O.render(sd_s, sd_c, b.deviation_network.variance, rays_o, rays_d, near, far, spp // 2, spp // 2, 4,
-                       jit[step["i"]], background_rgb, cos_anneal_ratio)
-        return out
-    b.renderer.render = oracle_render
-    # identical initial weights (both were built under torch.manual_seed(0); make it explicit)
-    for pa, pb in zip(a.params_to_train, b.params_to_train):
-        assert torch.equal(pa.detach().cpu(), pb.detach())
-
-    grads_a, grads_b, losses = None, None, []
-    for i in range(iters):
-        step["i"] = i
-        np.random.seed(1234 + i)
-        la = a.train_clip_iteration(i)
-        if i == 0:
-            grads_a = [p.grad.detach().cpu().clone() for p in a.params_to_train]
-        a.update_learning_rate()
-        np.random.seed(1234 + i)
-        lb = b.train_clip_iteration(i)
-        if i == 0:
-            grads_b = [p.grad.detach().clone() for p in b.params_to_train]
-        b.update_learning_rate()
-        losses.append((la.item(), lb.item()))
-    print("losses (hip, oracle):", losses)
-    for la, lb in losses:
-        assert abs(la - lb) < 2e-3 * max(1.0, abs(lb))
-    names = [n for net in (a.sdf_network, a.deviation_network, a.color_network) for n, _ in net.named_parameters()]
+def _check_grads(names, grads_a, grads_b, sdf_last_bias, rel_tol, cos_tol, bias_tol):
     worst = 0.0
-    sdf_last_bias = [n for n, _ in a.sdf_network.named_parameters() if n.endswith(".bias")][-1]
     seen_sdf = False
     gnorm = torch.cat([g.reshape(-1) for g in grads_b]).double().norm().item()
     for n, ga, gb in zip(names, grads_a, grads_b):
@@ -99,9 +52,10 @@ def test_train_clip_iteration_matches_oracle_driven_iteration():
         if n == sdf_last_bias and not seen_sdf:
             # d loss / d (sdf bias) = sum over all points of d loss / d sdf: the eikonal and the alpha terms pull both ways and
             # cancel to ~1e-3 of sum |d_sdf|, so 1e-3-level forward differences (f16 operands) move this ONE scalar by a few
-            # percent.  It is checked on its own with a wider bound; the other 128 entries go through the common check.
+            # percent.  It is checked on its own with a wider bound; the other entries go through the common check.
             seen_sdf = True
-            assert abs(ga.reshape(-1)[0] - gb.reshape(-1)[0]) < 0.1 * abs(gb.reshape(-1)[0]) + 1e-4
+            assert abs(ga.reshape(-1)[0] - gb.reshape(-1)[0]) < bias_tol * abs(gb.reshape(-1)[0]) + 1e-4, \
+                ("sdf bias[0]", ga.reshape(-1)[0].item(), gb.reshape(-1)[0].item())
             ga, gb = ga.reshape(-1)[1:], gb.reshape(-1)[1:]
         # tensors whose gradient is below 1e-4 of the whole gradient (the 3-entry weight_g of the extra colour head, fed only
         # by the CLIP term) are compared against that floor, not against their own norm
@@ -110,13 +64,102 @@ def test_train_clip_iteration_matches_oracle_driven_iteration():
         if gb.double().norm() < 1e-3 * gnorm:
             cos = 1.0
         worst = max(worst, rel)
-        if rel >= 5e-2:
-            d = (ga - gb).reshape(-1)
-            k = d.abs().argmax().item()
-            print("DIAG", n, "rel", rel, "argmax", k, ga.reshape(-1)[k].item(), gb.reshape(-1)[k].item(), "norms", ga.norm().item(), gb.norm().item(),
-                  "without it", ((d.double().norm() ** 2 - d[k].double() ** 2).sqrt() / gb.double().norm()).item())
-        assert rel < 5e-2 and cos > 0.995, (n, rel, cos)
+        assert rel < rel_tol and cos > cos_tol, (n, rel, cos)
+    return worst
+
+
+def _run_parity(res, spp, iters, small, silhouettes=False, rel_tol=2e-2, cos_tol=0.999, bias_tol=0.05, loss_tol=2e-3):
+    from oracle import iteration_oracle as IT
+    from oracle import neus_oracle as O
+    from avatarclip_amd.runner import clip_vit_random_state_dict, EllipsoidPrior
+    clip_sd = clip_vit_random_state_dict(0)
+    dev = torch.device("cuda")
+    over = {}
+    if silhouettes:
+        over = {"train.use_silhouettes": True, "train.max_ray_num": 900, "dataset.H": 256, "dataset.W": 256}
+    a = _make_runner(dev, res, spp, small, **over)
+    a.init_clip(clip_state_dict=clip_sd)
+    prior = EllipsoidPrior(device="cpu")
+    cams = [(np.array([0.35, 0.25, 1.45], np.float32), np.array([0.02, -0.03, 0.01], np.float32), 0.3, 1.2, 1),
+            (np.array([-1.1, 0.1, -0.9], np.float32), np.array([0.0, 0.05, 0.0], np.float32), 2.8, 4.0, 0)][:iters]
+    priors = [prior(c[0], c[1]) for c in cams]
+    step = {"i": 0}
+    a.init_smpl(prior_renderer=lambda eye, at: priors[step["i"]].to(dev))
+    a.update_learning_rate()
+    # ---------------- the oracle leg: plain tensors + Adam, no product code
+    sd_s = {n: p.detach().cpu().clone().requires_grad_() for n, p in a.sdf_network.named_parameters()}
+    sd_c = {n: p.detach().cpu().clone().requires_grad_() for n, p in a.color_network.named_parameters()}
+    var = a.deviation_network.variance.detach().cpu().clone().requires_grad_()
+    st = IT.OracleState(sd_s, sd_c, var, lr0=a.learning_rate, alpha=a.learning_rate_alpha, warm_up_end=a.warm_up_end,
+                        end_iter=a.end_iter)
+    texts = dict(prompt=a.encoded_text.cpu(), face_prompt=a.encoded_face_text.cpu(), back_prompt=a.encoded_back_text.cpu())
+    oconf = _oracle_conf(a, a.dataset.H)
+    names = [n for net in (a.sdf_network, a.deviation_network, a.color_network) for n, _ in net.named_parameters()]
+    sdf_last_bias = [n for n, _ in a.sdf_network.named_parameters() if n.endswith(".bias")][-1]
+    a_render = a.renderer.render
+    jit = {}
+    a.renderer.render = lambda *args, **kw: a_render(*args, jitter=jit["t"].to(dev), **kw)
+    bgs = {}
+    if silhouettes:   # the gaussian background (choice 1) is an input of both legs
+        a_draw = a.draw_background
+
+        def draw(view, choice_i=None):
+            g = torch.Generator().manual_seed(77 + step["i"])
+            bg = torch.clamp(torch.normal(torch.zeros(view.H, view.W, 1) + 0.5, torch.zeros(view.H, view.W, 1) + 0.2, generator=g), 0, 1).reshape(-1, 1)
+            bgs["bg"] = bg
+            bgd = bg.to(dev)
+            return 1, bgd, bgd.reshape(view.H, view.W, 1)[view.dilated_mask].reshape(-1, 1)
+        a.draw_background = draw
+    worst = 0.0
+    for i in range(iters):
+        step["i"] = i
+        eye, at, theta, phi, is_front = cams[i]
+        view = None
+        if silhouettes:   # ragged ray set: take the product's (pinned by tests/test_oracle_golden.py against the reference)
+            view = a.make_view(i, cams[i])
+            R = view.rays_o.shape[0]
+        else:
+            R = int(a.dataset.W // a.full_frame_resolution_level) ** 2
+        jit["t"] = torch.rand(R, 1, generator=torch.Generator().manual_seed(100 + i))
+        np.random.seed(4321 + i)
+        la = a.train_clip_iteration(i, camera=cams[i])
+        grads_a = [p.grad.detach().cpu().clone() for p in a.params_to_train]
+        a.update_learning_rate()
+        rs = np.random.RandomState(4321 + i)          # the product drew: light angles (2), ambience (1)  (main.py:433,440)
+        light = O.sphere_coord(theta + rs.uniform(-np.pi / 4, np.pi / 4), phi + rs.uniform(-np.pi / 4, np.pi / 4))
+        amb = float(rs.uniform(0, 0.2))
+        dr = IT.Draws(eye=eye, at=at, theta=theta, phi=phi, is_front=is_front, prior_rgb=priors[i], jitter=jit["t"],
+                      choice_i=1 if silhouettes else 3, background_rgb=bgs.get("bg"), light_dir=light, ambience=amb)
+        if silhouettes:
+            dr.dilated_mask, dr.rays_o, dr.rays_d, dr.W = view.dilated_mask.cpu(), view.rays_o.cpu(), view.rays_d.cpu(), view.W
+        ob = IT.train_clip_iteration(st, oconf, dr, clip_sd, texts, i)
+        print("iter %d  loss hip %.6f oracle %.6f   cosine %.5f / %.5f" % (i, la.item(), ob["loss"].item(),
+                                                                            a.last_stats["cosine"].item(), ob["cosine"].item()))
+        assert abs(la.item() - ob["loss"].item()) < loss_tol * max(1.0, abs(ob["loss"].item()))
+        assert abs(a.last_stats["cosine"].item() - ob["cosine"].item()) < 1e-3
+        w = _check_grads(names, grads_a, ob["grads"], sdf_last_bias, rel_tol, cos_tol, bias_tol)
+        worst = max(worst, w)
+        # after the Adam step the two weight sets stay together (a sign-flipped or mis-scaled gradient would show here at once)
+        for pa, pb in zip(a.params_to_train, st.params()):
+            assert (pa.detach().cpu() - pb.detach()).abs().max() < 3 * a.optimizer.param_groups[0]["lr"] + 1e-6
     print("worst per-tensor relative gradient error", worst)
+    return worst
+
+
+@gpu
+def test_train_clip_iteration_matches_independent_oracle_iteration_small_nets():
+    _run_parity(res=32, spp=32, iters=2, small=True)
+
+
+@gpu
+def test_train_clip_iteration_matches_independent_oracle_iteration_full_size_nets():
+    """BASELINE config 1 geometry (64 x 64 rays, S = I = 32) with the 256-wide networks of confs/examples."""
+    _run_parity(res=64, spp=64, iters=1, small=False)
+
+
+@gpu
+def test_train_clip_iteration_silhouette_rays_matches_independent_oracle_iteration():
+    _run_parity(res=256, spp=32, iters=1, small=True, silhouettes=True)
 
 
 @gpu

@@ -202,8 +202,10 @@ def test_render_matches_golden_on_reference_z(name):
     out = ren.render(rec["rays_o"].to(dev), rec["rays_d"].to(dev), rec["near"].to(dev), rec["far"].to(dev),
                      background_rgb=bg, cos_anneal_ratio=float(rec["cos_anneal"]), z_vals=rec["z_final"].to(dev))
     torch.cuda.synchronize()
-    for k, tol_max, tol_mean in (("color_fine", 2e-2, 1.5e-3), ("extra_color_fine", 2e-2, 1.5e-3),
-                                 ("weight_sum", 2e-2, 1.5e-3), ("weights", 3e-2, 1e-3)):
+    # SURVEY 8d gate for the f16/bf16-MFMA path: rendered RGB max-abs <= 5e-3 on [0,1]; measured: max 3e-4
+    # (shipped small checkpoint) / 1.7e-3 (full-size nets), mean 1e-5 / 5e-5 -- asserted at <= 3x the measured values
+    for k, tol_max, tol_mean in (("color_fine", 5e-3, 2e-4), ("extra_color_fine", 5e-3, 2e-4),
+                                 ("weight_sum", 5e-3, 2e-4), ("weights", 1e-2, 1e-4)):
         e = (out[k].detach().cpu() - rec["out_" + k]).abs()
         print(name, k, "max", e.max().item(), "mean", e.mean().item())
         assert e.max() < tol_max and e.mean() < tol_mean, k
@@ -229,7 +231,7 @@ def test_parameter_gradients_match_golden(name):
     loss.backward()
     torch.cuda.synchronize()
     print(name, "loss", loss.item(), "ref", rec["loss"].item())
-    assert abs(loss.item() - rec["loss"].item()) < 2e-2 * max(1.0, abs(rec["loss"].item()))
+    assert abs(loss.item() - rec["loss"].item()) < 2e-3 * max(1.0, abs(rec["loss"].item()))
     worst = 0.0
     for pfx, net in (("sdf.", sdf), ("var.", var), ("col.", col)):
         for n_, p in net.named_parameters():
@@ -241,7 +243,7 @@ def test_parameter_gradients_match_golden(name):
             cos = torch.nn.functional.cosine_similarity(g.reshape(1, -1).double(), ref.reshape(1, -1).double()).item()
             print("  %-22s rel %.3e cos %.5f |ref| %.3e" % (pfx + n_, re, cos, ref.norm().item()))
             worst = max(worst, re)
-            assert re < 3e-2 and cos > 0.999, (pfx + n_, re, cos)
+            assert re < 2e-2 and cos > 0.9995, (pfx + n_, re, cos)   # parameter gradients <= 1e-2..2e-2 (bf16 operands); measured <= 1.7e-2
 
 
 @gpu

@@ -136,6 +136,8 @@ class Engine:
     def _bufs(self, nblk_chunk):
         need = nblk_chunk * self.ptiles * 2048
         if self._panels is None or self._panels.numel() < need:
+            self._panels = None          # release the old buffer BEFORE the larger one is allocated (peak = need, not have + need)
+            torch.cuda.empty_cache()
             self._panels = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._panels
 
@@ -222,6 +224,7 @@ class Engine:
         R, S = z.shape
         per_ray_blocks = S / 32.0
         have = self._panels.numel() if self._panels is not None else 0
+        # 70 % of what is free once the current buffer is given back (it is released before a larger one is allocated)
         budget = max(min(self.PANEL_BYTES_BUDGET, (torch.cuda.mem_get_info(self.device)[0] + have) * 7 // 10), 1 << 28)
         max_blocks = max(1, budget // (self.ptiles * 2048))
         rays_per_chunk = max(1, int(max_blocks / per_ray_blocks) - 1)

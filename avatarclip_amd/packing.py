@@ -140,6 +140,10 @@ def spec_from_conf(sdf_conf: dict, col_conf: dict) -> NetSpec:
     ok = ok and int(sdf_conf["d_out"]) == H + 1 and int(col_conf["d_hidden"]) == H
     ok = ok and col_conf.get("mode") == "no_view_dir" and int(col_conf.get("multires_view", 0)) == 0
     ok = ok and float(sdf_conf.get("scale", 1.0)) == 1.0
+    # everything else the kernels hard-code: 3-D points in (weight norm is resolved on the host, either way works), a 6-D [x, n] colour input next to the feature vector, 3 sigmoid colour channels (+ the 3 of the extra head)
+    ok = ok and int(sdf_conf.get("d_in", 3)) == 3
+    ok = ok and int(col_conf.get("d_in", 6)) == 6 and int(col_conf.get("d_out", 3)) == 3
+    ok = ok and int(col_conf.get("d_feature", H)) == H and bool(col_conf.get("squeeze_out", True))
     if not ok:
         raise NotImplementedError(
             "avatarclip_amd kernels are instantiated for the two network shapes the reference ships "

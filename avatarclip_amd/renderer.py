@@ -75,9 +75,10 @@ class NeuSRenderer:
         bg, bg_mode = None, 0
         if background_rgb is not None and self.extra_color:
             bgt = background_rgb.to(rays_o.device).float()
-            if bgt.numel() == 3:
+            # by SHAPE ([1,3] colour vs [R,1] per-ray grey), not by element count: R == 3 is a legal ray count
+            if bgt.dim() == 2 and bgt.shape[0] == 1 and bgt.shape[1] == 3 or bgt.dim() == 1 and bgt.numel() == 3 and R != 3:
                 bg, bg_mode = bgt.reshape(3).contiguous(), 1
-            elif bgt.numel() == R:
+            elif bgt.numel() == R and (bgt.dim() == 1 or bgt.shape[-1] == 1):
                 bg, bg_mode = bgt.reshape(R).contiguous(), 2
             else:
                 raise ValueError("background_rgb must be [1,3] or [R,1] (main.py:387-415)")

@@ -34,6 +34,7 @@ _SIGS = {
     "avc_vit_attention_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "avc_probe_mfma": (c_int, [P, P, P, P, P, P, P]),
     "avc_weight_grad": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_long, P, P, c_int, c_int, c_int, P]),
+    "avc_rasterize_faces": (c_int, [P, P, c_int, c_int, c_float, c_float, P, P]),
     "avc_weight_grad_all": (c_int, [P, c_int, c_int, P, c_long, P, P, c_int, c_int, c_int, P]),
 }
 _OPTIONAL = {}

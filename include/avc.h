@@ -128,6 +128,16 @@ int avc_vit_attention_bwd(const float* qkv, const float* dout, float* dqkv, int 
 int avc_probe_mfma(const void* a_f16, const void* b_f16, float* d, const void* a_bf16, const void* b_bf16, float* d_bf,
                    void* stream);
 
+/* The forward pass of neural_renderer as the SMPL prior uses it (AvatarGen/AppearanceGen/models/utils.py:108-125,
+ * render_one_batch -> nr.Renderer(camera_mode='look')(vertices, faces, white textures); main.py:360): nearest front-facing
+ * face per pixel of an image_size x image_size grid (the caller passes the 2x super-sampled size and average-pools,
+ * anti_aliasing=True), value = that face's light intensity, 0 = background.
+ * faces[F,9]: per face three vertices (x, y in NDC after look + perspective, z = camera depth), the fill_back copies
+ * (reversed vertex order) included by the caller; light[F]: ambient + directional intensity per face (lighting.py, world
+ * space).  image[image_size, image_size], row 0 = top (rasterize.py's final flip applied). */
+int avc_rasterize_faces(const float* faces, const float* light, int F, int image_size, float near_, float far_,
+                        float* image, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

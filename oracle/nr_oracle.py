@@ -16,9 +16,13 @@ lighting,rasterize}.py and cuda/rasterize_cuda_kernel.cu of the PyTorch port):
   weights from the inverse of the pixel-space vertex matrix, clamped to [0,1] and renormalised; 1/z interpolated; nearest z in
   (near, far) wins; the image is finally flipped vertically (row 0 = top).
 
-Pinned against the reference-produced renders of data/zero_beta_tpose_render (tests/test_smpl_prior.py): the silhouettes of
-the 108 views at IoU >= 0.99 and the grey levels at a small mean error -- the only outputs of neural_renderer the reference
-ships.  What cannot be pinned offline: the exact tie-breaking of coincident depths (irrelevant for a constant texture).
+PARITY UNPINNED against neural_renderer itself: the package is absent offline, and the only neural_renderer outputs the
+reference ships (2 x 108 renders under data/zero_beta_*_render) show a POSED body whose vertices need the licensed SMPL
+files (the shipped zero_beta_smpl.obj is the un-posed template: arms horizontal, while both render sets have the arms
+down), so they cannot be re-rendered here.  What tests/test_smpl_prior.py does check against those renders: orientation,
+handedness, field of view and framing (the pose-independent torso / head / legs of the frontal views overlap), and the
+grey-level range produced by the ambient + directional light and the 2x2 anti-aliasing (31 = one of four sub-samples at
+ambient 0.5, up to 251).
 """
 import numpy as np
 
@@ -59,12 +63,16 @@ def face_light(v_world, faces, ambient=0.5, directional=0.5, direction=(0., 1., 
     return ambient + directional * np.maximum(c, 0), ambient + directional * np.maximum(-c, 0)
 
 
-def rasterize(v_ndc, faces, light_fwd, light_rev, image_size=256, anti_aliasing=True, near=0.1, far=100.0):
-    """-> grey image [image_size, image_size] (float64, row 0 = top), alpha mask."""
+def rasterize(v_ndc, faces, light_fwd, light_rev, image_size=256, anti_aliasing=True, near=0.1, far=100.0, dtype=np.float32):
+    """-> grey image [image_size, image_size] (row 0 = top).  dtype float32 follows the CUDA kernel's arithmetic (and the HIP
+    kernel's) operation by operation; float64 is available for sensitivity checks."""
     is_ = image_size * 2 if anti_aliasing else image_size
-    img = np.zeros((is_, is_))
-    zbuf = np.full((is_, is_), np.inf)
-    fv = v_ndc[faces]                                         # [F,3,3]
+    img = np.zeros((is_, is_), dtype)
+    zbuf = np.full((is_, is_), np.inf, dtype)
+    is_f = dtype(is_)
+    fv = np.asarray(v_ndc, dtype)[faces]                      # [F,3,3]
+    light_fwd, light_rev = np.asarray(light_fwd, dtype), np.asarray(light_rev, dtype)
+    near, far = dtype(near), dtype(far)
     for rev in (False, True):
         tri = fv[:, ::-1] if rev else fv
         light = light_rev if rev else light_fwd
@@ -80,26 +88,25 @@ def rasterize(v_ndc, faces, light_fwd, light_rev, image_size=256, anti_aliasing=
             lo_x, lo_y, hi_x, hi_y = max(lo_x, 0), max(lo_y, 0), min(hi_x, is_ - 1), min(hi_y, is_ - 1)
             if lo_x > hi_x or lo_y > hi_y:
                 continue
-            xi = np.arange(lo_x, hi_x + 1)[None, :]
-            yi = np.arange(lo_y, hi_y + 1)[:, None]
-            xp = (2.0 * xi + 1 - is_) / is_
-            yp = (2.0 * yi + 1 - is_) / is_
+            xi = np.arange(lo_x, hi_x + 1, dtype=dtype)[None, :]
+            yi = np.arange(lo_y, hi_y + 1, dtype=dtype)[:, None]
+            xp = (dtype(2) * xi + dtype(1) - is_f) / is_f
+            yp = (dtype(2) * yi + dtype(1) - is_f) / is_f
             out = ((yp - y0[k]) * (x1[k] - x0[k]) < (xp - x0[k]) * (y1[k] - y0[k])) | \
                   ((yp - y1[k]) * (x2[k] - x1[k]) < (xp - x1[k]) * (y2[k] - y1[k])) | \
                   ((yp - y2[k]) * (x0[k] - x2[k]) < (xp - x2[k]) * (y0[k] - y2[k]))
             if out.all():
                 continue
-            p = 0.5 * (tri[k, :, :2] * is_ + is_ - 1)        # pixel-space vertices
+            p = dtype(0.5) * (tri[k, :, :2] * is_f + is_f - dtype(1))        # pixel-space vertices
             inv = np.array([[p[1, 1] - p[2, 1], p[2, 0] - p[1, 0], p[1, 0] * p[2, 1] - p[2, 0] * p[1, 1]],
                             [p[2, 1] - p[0, 1], p[0, 0] - p[2, 0], p[2, 0] * p[0, 1] - p[0, 0] * p[2, 1]],
                             [p[0, 1] - p[1, 1], p[1, 0] - p[0, 0], p[0, 0] * p[1, 1] - p[1, 0] * p[0, 1]]])
             den = p[2, 0] * (p[0, 1] - p[1, 1]) + p[0, 0] * (p[1, 1] - p[2, 1]) + p[1, 0] * (p[2, 1] - p[0, 1])
             if den == 0:
                 continue
-            inv = inv / den
-            w = [np.clip(inv[j, 0] * xi + inv[j, 1] * yi + inv[j, 2], 0, 1) for j in range(3)]
-            ws = np.maximum(w[0] + w[1] + w[2], 1e-10)
-            zp = 1.0 / ((w[0] / z0[k] + w[1] / z1[k] + w[2] / z2[k]) / ws)
+            w = [np.clip((inv[j, 0] * xi + inv[j, 1] * yi + inv[j, 2]) / den, 0, 1) for j in range(3)]
+            ws = np.maximum(w[0] + w[1] + w[2], dtype(1e-10))
+            zp = dtype(1) / ((w[0] / z0[k] + w[1] / z1[k] + w[2] / z2[k]) / ws)
             ok = (~out) & (zp > near) & (zp < far)
             sub_z = zbuf[lo_y:hi_y + 1, lo_x:hi_x + 1]
             sub_i = img[lo_y:hi_y + 1, lo_x:hi_x + 1]
@@ -112,11 +119,11 @@ def rasterize(v_ndc, faces, light_fwd, light_rev, image_size=256, anti_aliasing=
     return img
 
 
-def render(v_world, faces, eye, direction, image_size=256):
+def render(v_world, faces, eye, direction, image_size=256, dtype=np.float32):
     """nr.Renderer(camera_mode='look' | 'look_at')(vertices, faces, white textures) -> grey [H,W] in [0,1]."""
     lf, lr = face_light(np.asarray(v_world, np.float64), faces)
     v = perspective(look(v_world, eye, direction))
-    return rasterize(v, faces, lf, lr, image_size)
+    return rasterize(v, faces, lf, lr, image_size, dtype=dtype)
 
 
 def render_one_batch(v, faces, eye, at):

@@ -1,0 +1,98 @@
+"""the SMPL prior (posed mesh -> silhouette / grey render) without smplx / neural_renderer.
+  CPU: linear blend skinning against an independent numpy restatement on a synthetic skeleton; the neural_renderer
+       restatement's conventions against the reference-produced renders (framing / orientation / grey range -- the shipped
+       renders show a posed body, so this is NOT a pin of the rasteriser, see oracle/nr_oracle.py);
+  GPU: the HIP rasteriser (avc_rasterize_faces behind smpl_prior.MeshPrior) against the restatement on the SMPL template."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+gpu = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "smpl_views.npz")
+
+
+def test_lbs_matches_numpy_restatement_on_a_synthetic_skeleton():
+    from avatarclip_amd import smpl_lbs
+    from oracle import lbs_oracle as LO
+    rng = np.random.RandomState(0)
+    V, J = 200, 6
+    parents = np.array([-1, 0, 1, 1, 3, 0])
+    v = rng.randn(V, 3) * 0.3
+    Jreg = np.abs(rng.rand(J, V)); Jreg /= Jreg.sum(1, keepdims=True)
+    W = np.abs(rng.rand(V, J)) ** 3; W /= W.sum(1, keepdims=True)
+    posedirs = rng.randn((J - 1) * 9, V * 3) * 0.01
+    pose = rng.randn(J, 3) * 0.6
+    rot = np.stack([LO.rodrigues(p) for p in pose])
+    ref_v, ref_j = LO.lbs(v, rot, posedirs, Jreg, parents, W)
+    t = lambda a: torch.from_numpy(np.asarray(a)).double()
+    rot_t = smpl_lbs.batch_rodrigues(t(pose))
+    assert np.abs(rot_t.numpy() - rot).max() < 1e-9
+    out_v, out_j = smpl_lbs.lbs(t(v)[None], rot_t[None], t(posedirs), t(Jreg), torch.from_numpy(parents), t(W))
+    assert np.abs(out_v[0].numpy() - ref_v).max() < 1e-9 and np.abs(out_j[0].numpy() - ref_j).max() < 1e-9
+    # the T pose of main.py:307-309 (root turned by pi/2 about x) followed by rot_mat is a pure translation of the template
+    pose0 = np.zeros((J, 3)); pose0[0, 0] = np.pi / 2
+    r0 = smpl_lbs.batch_rodrigues(t(pose0))
+    v0, _ = smpl_lbs.lbs(t(v)[None], r0[None], t(posedirs) * 0, t(Jreg), torch.from_numpy(parents), t(W))
+    from oracle.nr_oracle import ROT_MAT
+    d = v0[0].numpy() @ ROT_MAT - v
+    assert np.abs(d - d[0]).max() < 1e-7      # (the 1e-8 epsilon inside batch_rodrigues)
+
+
+def test_renderer_restatement_conventions_against_reference_renders():
+    from oracle import nr_oracle as NR
+    z = np.load(GOLD)
+    V, Fc = z["mesh_v"].astype(np.float64), z["mesh_f"]
+    ims, poses = z["tpose_images"], z["tpose_poses"]
+    assert sorted(np.unique(ims))[1] in (31, 32) and ims.max() >= 240      # 1/4 coverage x ambient 0.5 ... ambient + directional
+    t = np.array([0.0, 0.288, 0.211])     # pelvis offset of the posed body (fitted on the legs; the SMPL joint regressor is not available)
+    for k in (3, 57):                     # camera in front of / behind the body, elevation 0
+        eye = poses[k][:3, 3]
+        img = NR.render(V + t, Fc, eye, -eye / np.linalg.norm(eye))
+        a, b = img > 0, ims[k] > 0
+        ra, rb = np.nonzero(a.any(1))[0], np.nonzero(b.any(1))[0]
+        assert abs(ra.min() - rb.min()) <= 12 and abs(ra.max() - rb.max()) <= 12         # head top / feet rows: same framing, upright
+        ca, cb = np.nonzero(a.any(0))[0], np.nonzero(b.any(0))[0]
+        assert abs(0.5 * (ca.min() + ca.max()) - 0.5 * (cb.min() + cb.max())) <= 4       # centred alike
+        band = slice(int(0.5 * (cb.min() + cb.max())) - 10, int(0.5 * (cb.min() + cb.max())) + 11)   # torso / head column band
+        inter, union = (a[:, band] & b[:, band]).sum(), (a[:, band] | b[:, band]).sum()
+        assert inter / union > 0.75     # pose-independent part only roughly (different arm / leg pose, fitted pelvis offset)
+        both = a & b
+        assert abs(float(img[both].mean() * 255) - float(ims[k][both].mean())) < 25     # same light model (grey level of the body)
+
+
+@gpu
+def test_hip_rasteriser_matches_restatement():
+    import time
+    from avatarclip_amd.smpl_prior import MeshPrior
+    from oracle import nr_oracle as NR
+    z = np.load(GOLD)
+    V, Fc = z["mesh_v"], z["mesh_f"]
+    prior = MeshPrior(V, Fc, device="cuda")
+    cams = [(np.array([0.2, 0.3, 1.6]), np.array([0.0, -0.1, 0.05])), (np.array([-1.3, -0.4, -0.9]), np.array([0.05, 0.1, 0.0])),
+            (np.array([0.05, 1.5, 0.6]), np.array([0.0, 0.2, 0.0]))]
+    for eye, at in cams:
+        out = prior(eye, at).cpu().numpy()
+        ref = NR.render_one_batch(V.astype(np.float64), Fc, eye, at).astype(np.float32)
+        assert out.shape == (256, 256, 3) and np.array_equal(out[..., 0], out[..., 1])
+        mism = ((out[..., 0] > 0) != (ref[..., 0] > 0)).sum()
+        inter, union = ((out[..., 0] > 0) & (ref[..., 0] > 0)).sum(), ((out[..., 0] > 0) | (ref[..., 0] > 0)).sum()
+        d = np.abs(out - ref)
+        print("eye", eye, "coverage", (ref[..., 0] > 0).mean(), "mask mismatches", mism, "IoU", inter / union, "max |d|", d.max(), "mean |d|", d.mean())
+        assert inter / union > 0.999 and d.mean() < 1e-4 and (d > 0.26).sum() <= 4    # a flipped edge sub-sample moves a pixel by <= 1/4
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(20):
+        prior(cams[0][0], cams[0][1])
+    torch.cuda.synchronize()
+    print("MeshPrior render: %.3f ms per 256x256 view (13776 faces, 2x super-sampling)" % ((time.time() - t0) / 20 * 1e3))
+    # as the Runner's prior: mask / colour target of train_clip
+    import bench
+    from avatarclip_amd.runner import Runner
+    conf = bench.make_conf(64, 32, small=True)
+    r = Runner(None, mode="train_clip", conf=conf, device=torch.device("cuda"))
+    r.init_clip()
+    r.init_smpl(prior)
+    loss = r.train_clip_iteration(1)
+    assert torch.isfinite(loss)

@@ -185,7 +185,15 @@ def main():
     conf = make_conf(args.res, args.spp, args.small)
     runner = Runner(None, mode="train_clip", conf=conf, device=dev)
     runner.init_clip()
-    runner.init_smpl()
+    # the silhouette / colour prior: the SMPL template mesh (reference data/zero_beta_smpl.obj, packed in the test fixture) through
+    # the HIP rasteriser with neural_renderer's conventions -- the same per-iteration work as main.py:360
+    mesh_npz = os.path.join(ROOT, "tests", "golden", "smpl_views.npz")
+    if os.path.exists(mesh_npz):
+        from avatarclip_amd.smpl_prior import MeshPrior
+        z = np.load(mesh_npz)
+        runner.init_smpl(MeshPrior(z["mesh_v"], z["mesh_f"], device=dev))
+    else:
+        runner.init_smpl()
     runner.update_learning_rate()
 
     def step(i):

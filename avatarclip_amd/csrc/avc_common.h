@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b8 __attribute__((ext_vector_type(8)));

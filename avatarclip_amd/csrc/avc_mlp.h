@@ -243,6 +243,97 @@ __device__ __forceinline__ void layer2_s(ST& st, const V* __restrict__ blob, int
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Operand panels of the training path (mirrored by packing.py: build_layout).  Every operand of every weight-gradient
+// product is stored ONCE, in the layout the producing wavefront holds it in: per 32-point block and 32-feature tile the two
+// B-operand fragments [k-step e][lane][8 x 16 bit] (lane = point + 32 * half), 2 KiB per tile.  Forward-type operands
+// (h, g_a, feature, r, [x,n], PE) are f16 and written by the forward kernel, gradient-type operands (gbar_h, abar, delta,
+// ybar) are bf16 and written by the backward kernel; the sweeps of both kernels read tiles back as they are (no
+// transposition), the weight-gradient kernel transposes them on the matrix core when it loads them (avc_wgrad.hip).
+// ---------------------------------------------------------------------------------------------------------------
+template <class N>
+struct PanelLayout {
+  static constexpr int HT = N::HT, ST = N::ST, NM = N::NMID, NC = N::NCMID;
+  static constexpr int P_H0 = 0;                    // pe values (2 tiles)                         f16, forward
+  static constexpr int P_GB0 = P_H0 + 2;            // gbar_h0 (2)                                 bf16, backward
+  static constexpr int P_H1 = P_GB0 + 2;            // h1                                          f16, forward
+  static constexpr int P_HM = P_H1 + HT;            // hm[NM]
+  static constexpr int P_HS = P_HM + NM * HT;       // hs (ST)
+  static constexpr int P_GBH1 = P_HS + ST;          // gbar_h1                                     bf16, backward
+  static constexpr int P_GBHM = P_GBH1 + HT;        // gbar_hm[NM]
+  static constexpr int P_GBHS = P_GBHM + NM * HT;   // gbar_hs (ST)
+  static constexpr int P_GA1 = P_GBHS + ST;         // g_a1                                        f16, forward
+  static constexpr int P_GAM = P_GA1 + HT;          // g_am[NM]
+  static constexpr int P_GAS = P_GAM + NM * HT;     // g_as (ST)
+  static constexpr int P_AB1 = P_GAS + ST;          // abar_1                                      bf16, backward
+  static constexpr int P_ABM = P_AB1 + HT;          // abar_m[NM]
+  static constexpr int P_ABS = P_ABM + NM * HT;     // abar_s (ST)
+  static constexpr int P_DFEAT = P_ABS + ST;        // ybar[1:] (HT)                               bf16, backward
+  static constexpr int P_SDF = P_DFEAT + HT;        // feature 0 = d_sdf (1)                       bf16, backward
+  static constexpr int P_ONE = P_SDF + 1;           // feature 0 = 1 (1)                           bf16, backward
+  static constexpr int P_FEAT = P_ONE + 1;          // feature (HT)                                f16, forward
+  static constexpr int P_XN = P_FEAT + HT;          // [x, n] (1)                                  f16, forward
+  static constexpr int P_R1 = P_XN + 1;             // r1 (HT)                                     f16, forward
+  static constexpr int P_R2 = P_R1 + HT;            // r2 (HT, only NC==1)                         f16, forward
+  static constexpr int P_D1 = P_R2 + NC * HT;       // delta1 (HT)                                 bf16, backward
+  static constexpr int P_D2 = P_D1 + HT;            // delta2 (HT, only NC==1)
+  static constexpr int P_DO = P_D2 + NC * HT;       // delta_o (1)
+  static constexpr int P_TILES = P_DO + 1;
+  static constexpr int MASK_U16 = 2 * HT * 64;      // ReLU masks of r1 / r2 per 32-point block: [layer][tile][lane] x 16 bits
+};
+// the no-grad forward parks only what its own normal sweep reads back (h1, hm, feature), in a per-wavefront slot it reuses
+template <class N>
+struct ScratchLayout {
+  static constexpr int HT = N::HT, NM = N::NMID;
+  static constexpr int P_H1 = 0, P_HM = HT, P_FEAT = HT + NM * HT, P_TILES = P_FEAT + HT;
+  static constexpr int P_H0 = 0, P_HS = 0, P_GA1 = 0, P_GAM = 0, P_GAS = 0, P_XN = 0, P_R1 = 0, P_R2 = 0;   // never written
+};
+
+// Panel addressing: `ub` = wave-uniform base of the block's panels (SGPR pair), `off` = lane * 16 (ONE VGPR shared by every
+// access); the tile base is formed on the scalar unit and kept opaque, so that hipcc emits the saddr form
+// (global_store v_off, v_data, s[base]) instead of one 64-bit VGPR address pair per tile (those pairs were being
+// computed early and spilled: +130 spilled registers in the training forward kernel).
+struct PanelPtr {
+  AVC_GLOBAL char* ub;
+  unsigned off;
+};
+__device__ __forceinline__ PanelPtr panel_ptr(char* base, int lane) {
+  const unsigned long long v = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  PanelPtr p;
+  p.ub = (AVC_GLOBAL char*)(((unsigned long long)hi << 32) | lo);
+  p.off = (unsigned)lane * 16u;
+  return p;
+}
+template <typename V> __device__ __forceinline__ AVC_GLOBAL V* tile_addr(const PanelPtr& pp, int tile) {
+  AVC_GLOBAL char* tb = pp.ub + (long)tile * 2048;
+  asm("" : "+s"(tb));
+  return (AVC_GLOBAL V*)(tb + pp.off);
+}
+// KEEP = read back soon by the same kernel (normal cache policy), otherwise streamed past the caches (consumed by a later launch)
+// (No predicate: wavefronts past the end of the point set write to the SINK block that follows the last real block of the
+// panel buffer -- a branch around every store splits the scheduling regions of the epilogues and costs ~110 spilled registers.)
+template <bool KEEP, typename V>
+__device__ __forceinline__ void tile_store(const PanelPtr& pp, int tile, const V& f0, const V& f1) {
+  AVC_GLOBAL V* p = tile_addr<V>(pp, tile);
+  if (KEEP) {
+    p[0] = f0;
+    p[64] = f1;
+  } else {
+    AVC_NT_STORE(f0, &p[0]);
+    AVC_NT_STORE(f1, &p[64]);
+  }
+}
+template <typename V> struct FragPair { V a0, a1; };     // the two k-step fragments of a panel tile
+template <bool NT, typename V>
+__device__ __forceinline__ FragPair<V> tile_load(const PanelPtr& pp, int tile) {
+  const AVC_GLOBAL V* p = tile_addr<V>(pp, tile);
+  FragPair<V> d;
+  if (NT) { d.a0 = AVC_NT_LOAD(&p[0]); d.a1 = AVC_NT_LOAD(&p[64]); }
+  else { d.a0 = p[0]; d.a1 = p[64]; }
+  return d;
+}
+
 // SDF value only (avc_sdf_forward): same layers as sdf_trunk but every activation array dies as soon as the next layer
 // has consumed it, which keeps the kernel at two wavefronts per SIMD.
 template <class N, class ST, typename TP>

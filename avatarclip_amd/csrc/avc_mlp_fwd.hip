@@ -43,42 +43,38 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_sdf_kernel(PointSrc ps, long
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// avc_render_points_fwd: sdf + normal + colour.  The normal sweep needs sigma(h_l) of every trunk layer in REVERSE order;
-// keeping h1..h_s of 32 points in registers is 248 VGPRs of state on top of the working set, which the first version of
-// this kernel paid for with 331 spilled registers -- PMC: 114 GB of scratch traffic per 16.8 M points, i.e. the kernel
-// was bound by its own spills (HBM), not by MFMA.  Here the three H-wide activations are parked EXPLICITLY in a
-// per-wavefront slot (frag layout, one coalesced 1-KiB store per k-step, 64 KiB per 32 points incl. the feature vector
-// instead of ~217 KiB of spill traffic; 2048 slots = 134 MB, inside the 256 MB Infinity Cache) and read back tile by tile in the epilogues of the
-// sweep; h_s never leaves the registers (it is consumed at once by g_a,s and by the feature layer).
-// Persistent workgroups (the slot is reused for every block a wave processes).  Plain (temporal) accesses: the slot is
-// re-read within the same block, and non-temporal hints measured 5 % slower here (they pay off in the backward kernel).
+// avc_render_points_fwd / avc_render_points_fwd_train: sdf + normal + colour.  The normal sweep needs sigma(h_l) of every
+// trunk layer in REVERSE order; keeping h1..h_s of 32 points in registers is 248 VGPRs of state on top of the working set
+// (the first version of this kernel paid for it with 331 spilled registers).  The H-wide activations therefore leave the
+// registers as 2-KiB tiles in fragment layout (one coalesced 1-KiB store per k-step) and are read back tile by tile in the
+// epilogues of the sweep; h_s never leaves the registers (it is consumed at once by g_a,s and by the feature layer).
+//   TRAIN = false: the tiles go to a per-wavefront slot that is reused for every block (2048 slots x 64 KiB = 134 MB).
+//   TRAIN = true : the tiles go to the block's operand panels (PanelLayout) together with everything else the backward pass and
+//                  the weight-gradient products need from the forward pass -- PE values, h_s, g_a of every layer, the feature
+//                  vector, [x,n], r1, r2 and the ReLU masks -- so that the backward kernel recomputes NOTHING of the forward
+//                  (renderer.py:221-232 runs once per iteration, as in the reference).  The extra stores are streaming
+//                  (non-temporal) and ride under a kernel that is bound by its matrix / vector work.
+// Persistent workgroups.  Plain (temporal) accesses for the tiles that are re-read within the same block.
 // ---------------------------------------------------------------------------------------------------------------
-template <class N>
-struct FwdScratch {
-  static constexpr int S_H1 = 0;
-  static constexpr int S_HM = S_H1 + N::HK;
-  static constexpr int S_FEAT = S_HM + N::NMID * N::HK;   // feature vector, parked across the normal sweep
-  static constexpr int S_KSTEPS = S_FEAT + N::HK;
-};
-struct FP1 { h8 a0, a1; };   // two k-steps of a parked activation (loaded one MFMA chain before their epilogue)
 template <typename P> __device__ __forceinline__ P launder_ptr(P p) {
   asm volatile("" : "+s"(p));
   return p;
 }
 
-template <class N>
+template <class N, bool TRAIN>
 __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, long npts, const h8* __restrict__ Wf0,
                                                                   const float* __restrict__ T0, AvcOffsets o,
                                                                   float* __restrict__ sdf_out, float* __restrict__ normal_out,
-                                                                  float* __restrict__ rgb_out, char* __restrict__ scratch) {
-  typedef FwdScratch<N> L;
+                                                                  float* __restrict__ rgb_out, char* __restrict__ store,
+                                                                  unsigned short* __restrict__ masks) {
+  typedef typename std::conditional<TRAIN, PanelLayout<N>, ScratchLayout<N>>::type L;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   typedef StageT<FWD_G> ST;
   const int lane = threadIdx.x & 63, h = lane >> 5, p = lane & 31;
   const int wv = threadIdx.x >> 6;
   const long nblk = (npts + 31) >> 5;
   const long wslot = (long)blockIdx.x * FWD_WPB + wv;
-  char* scr0 = scratch + wslot * (long)L::S_KSTEPS * 1024 + lane * 16;
+  char* slot0 = store + wslot * (long)L::P_TILES * 2048;   // TRAIN = false: this wave's private slot
   ST sg = stage_init<FWD_G>(lds);
   stage_issue(sg, nxt<N, OFF_W0>(sg, Wf0, o), 0);
   const lds_tab_t T = tab_to_lds(lds + ST::LDS_BYTES, T0, o.v[OFF_TAB_END]);
@@ -86,9 +82,10 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
   for (long blk0 = (long)blockIdx.x * FWD_WPB; blk0 < nblk; blk0 += (long)gridDim.x * FWD_WPB) {
     // opaque per iteration: otherwise LICM hoists the loop-invariant addresses out of the loop and spills them
     const h8* Wf = launder_ptr(Wf0);
-    asm volatile("" : "+v"(scr0));
-    AVC_GLOBAL h8* scr = as_global(reinterpret_cast<h8*>(scr0));
     const long blk = blk0 + wv;
+    // TRAIN: block nblk of the panel / mask buffers is a sink for the wavefronts past the end (they walk the tile sequence for the barriers)
+    const PanelPtr tiles = panel_ptr(TRAIN ? store + (blk < nblk ? blk : nblk) * (long)L::P_TILES * 2048 : slot0, lane);
+    AVC_GLOBAL unsigned short* mk = as_global(masks) + (TRAIN ? (blk < nblk ? blk : nblk) * (long)PanelLayout<N>::MASK_U16 + lane : 0);
     long i = blk * 32 + p;
     const bool valid = i < npts;
     if (!valid) i = npts - 1;
@@ -109,35 +106,44 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
       }
       h8 pef[3];
       pe_to_frags_f16(pe, x, h, pef);
-#define AVC_F_PARK(OFFB, OUT, SCR)                                                           \
+      if constexpr (TRAIN) {
+        h8 zf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) zf[j] = (_Float16)0.f;
+        tile_store<false>(tiles, L::P_H0, pef[0], pef[1]);
+        tile_store<false>(tiles, L::P_H0 + 1, pef[2], zf);
+      }
+#define AVC_F_PARK(OFFB, OUT, PT)                                                            \
   AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
           _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);  \
           acc_to_frags(a, OUT[2 * t], OUT[2 * t + 1]);                                        \
-          scr[((SCR) + 2 * t) * 64] = OUT[2 * t]; scr[((SCR) + 2 * t + 1) * 64] = OUT[2 * t + 1];)
+          tile_store<true>(tiles, (PT) + t, OUT[2 * t], OUT[2 * t + 1]);)
 #define AVC_F_LAST(OFFB)                                                                      \
   AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
           _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);  \
           load16(T + o.v[OFF_WL0_ACC], t, h, b);                                              \
           _Pragma("unroll") for (int r = 0; r < 16; ++r) part += b[r] * a[r];                 \
           acc_to_frags(a, hs[2 * t], hs[2 * t + 1]);                                          \
+          if constexpr (TRAIN) tile_store<false>(tiles, L::P_HS + t, hs[2 * t], hs[2 * t + 1]); \
           float w0[8], w1[8];                                                                 \
           load8(T + o.v[OFF_WL0_FRAG], 2 * t, h, w0); load8(T + o.v[OFF_WL0_FRAG], 2 * t + 1, h, w1); \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                     \
             g_s[2 * t][j] = (_Float16)(w0[j] * sig_from_h(a[j]));                             \
             g_s[2 * t + 1][j] = (_Float16)(w1[j] * sig_from_h(a[8 + j])); }                   \
-          pin2(g_s[2 * t], g_s[2 * t + 1]);)
+          pin2(g_s[2 * t], g_s[2 * t + 1]);                                                   \
+          if constexpr (TRAIN) tile_store<false>(tiles, L::P_GAS + t, g_s[2 * t], g_s[2 * t + 1]);)
       {
         h8 h1[N::HK];
-        layer_s<h8, 3, N::HT>(sg, Wf, o.v[OFF_W0], nxt<N, OFF_WM0>(sg, Wf, o), pef, AVC_F_PARK(OFF_B0, h1, L::S_H1));
+        layer_s<h8, 3, N::HT>(sg, Wf, o.v[OFF_W0], nxt<N, OFF_WM0>(sg, Wf, o), pef, AVC_F_PARK(OFF_B0, h1, L::P_H1));
         h8 hm0[N::HK];
         if constexpr (N::NMID == 2) {
-          layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wf, o), h1, AVC_F_PARK(OFF_BM0, hm0, L::S_HM));
+          layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wf, o), h1, AVC_F_PARK(OFF_BM0, hm0, L::P_HM));
           h8 hm1[N::HK];
           layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wf, o), hm0,
-                                    AVC_F_PARK(OFF_BM1, hm1, L::S_HM + N::HK));
+                                    AVC_F_PARK(OFF_BM1, hm1, L::P_HM + N::HT));
           layer_s<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], nxt<N, OFF_WL>(sg, Wf, o), hm1, AVC_F_LAST(OFF_BS));
         } else {
-          layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wf, o), h1, AVC_F_PARK(OFF_BM0, hm0, L::S_HM));
+          layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wf, o), h1, AVC_F_PARK(OFF_BM0, hm0, L::P_HM));
           layer_s<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], nxt<N, OFF_WL>(sg, Wf, o), hm0, AVC_F_LAST(OFF_BS));
         }
       }
@@ -149,27 +155,29 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
         _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = acc[r] + b[r];
         h8 f0, f1;
         acc_to_frags(a, f0, f1);
-        scr[(L::S_FEAT + 2 * t) * 64] = f0; scr[(L::S_FEAT + 2 * t + 1) * 64] = f1;
+        tile_store<true>(tiles, L::P_FEAT + t, f0, f1);
       ));
     }
     // ---------------------------------------------------------------- normal sweep: g_h(prev) = W^T g_a ; g_a(prev) = g_h sigma(h_prev)
     float n[3];
     {
-#define AVC_F_NSTEP(OUT, SH)                                                                              \
-  AVC_PRE(FP1 d; d.a0 = scr[((SH) + 2 * t) * 64]; d.a1 = scr[((SH) + 2 * t + 1) * 64]; return d;),         \
-  AVC_EPID(FP1, _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                             \
+#define AVC_F_NSTEP(OUT, PH, PG)                                                                          \
+  AVC_PRE(return tile_load<false, h8>(tiles, (PH) + t);),                                                       \
+  AVC_EPID(FragPair<h8>, _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                    \
             OUT[2 * t][j] = (_Float16)(acc[j] * sig_from_h((float)d.a0[j]));                                \
             OUT[2 * t + 1][j] = (_Float16)(acc[8 + j] * sig_from_h((float)d.a1[j])); }                      \
-          pin2(OUT[2 * t], OUT[2 * t + 1]);)
+          pin2(OUT[2 * t], OUT[2 * t + 1]);                                                                 \
+          if constexpr (TRAIN) tile_store<false>(tiles, (PG) + t, OUT[2 * t], OUT[2 * t + 1]);)
       h8 g[N::HK];
       h8 g2[N::HK];
       if constexpr (N::NMID == 2) {
-        layer_sq<h8, N::SK, N::HT>(sg, Wf, o.v[OFF_WST], nxt<N, OFF_WM1T>(sg, Wf, o), g_s, AVC_F_NSTEP(g, L::S_HM + N::HK));
-        layer_sq<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1T], nxt<N, OFF_WM0T>(sg, Wf, o), g, AVC_F_NSTEP(g2, L::S_HM));
-        layer_sq<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0T], nxt<N, OFF_W0T>(sg, Wf, o), g2, AVC_F_NSTEP(g, L::S_H1));
+        layer_sq<h8, N::SK, N::HT>(sg, Wf, o.v[OFF_WST], nxt<N, OFF_WM1T>(sg, Wf, o), g_s,
+                                   AVC_F_NSTEP(g, L::P_HM + N::HT, L::P_GAM + N::HT));
+        layer_sq<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1T], nxt<N, OFF_WM0T>(sg, Wf, o), g, AVC_F_NSTEP(g2, L::P_HM, L::P_GAM));
+        layer_sq<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0T], nxt<N, OFF_W0T>(sg, Wf, o), g2, AVC_F_NSTEP(g, L::P_H1, L::P_GA1));
       } else {
-        layer_sq<h8, N::SK, N::HT>(sg, Wf, o.v[OFF_WST], nxt<N, OFF_WM0T>(sg, Wf, o), g_s, AVC_F_NSTEP(g2, L::S_HM));
-        layer_sq<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0T], nxt<N, OFF_W0T>(sg, Wf, o), g2, AVC_F_NSTEP(g, L::S_H1));
+        layer_sq<h8, N::SK, N::HT>(sg, Wf, o.v[OFF_WST], nxt<N, OFF_WM0T>(sg, Wf, o), g_s, AVC_F_NSTEP(g2, L::P_HM, L::P_GAM));
+        layer_sq<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0T], nxt<N, OFF_W0T>(sg, Wf, o), g2, AVC_F_NSTEP(g, L::P_H1, L::P_GA1));
       }
       float part[3] = {0.f, 0.f, 0.f};
       const auto wpe = T + o.v[OFF_WL0_PE] + h * 24;
@@ -194,20 +202,37 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
 #pragma unroll
         for (int c = 0; c < 3; ++c) { xn[0][c] = (_Float16)x[c]; xn[0][3 + c] = (_Float16)n[c]; }
       }
+      if constexpr (TRAIN) {
+        h8 zf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) zf[j] = (_Float16)0.f;
+        tile_store<false>(tiles, L::P_XN, xn[0], zf);
+      }
       h8 feat[N::HK];
 #pragma unroll
-      for (int s = 0; s < N::HK; ++s) feat[s] = scr[(L::S_FEAT + s) * 64];
-#define AVC_F_RELU(OFFB, OUT)                                                                 \
+      for (int t = 0; t < N::HT; ++t) {
+        const FragPair<h8> d = tile_load<false, h8>(tiles, L::P_FEAT + t);
+        feat[2 * t] = d.a0;
+        feat[2 * t + 1] = d.a1;
+      }
+      // ReLU layers; TRAIN: the activations go out as weight-gradient operands and their sign bits (16 per tile and lane) as the
+      // masks of the backward pass
+#define AVC_F_RELU(OFFB, OUT, PT, ML)                                                         \
   AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
-          _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r] + b[r], 0.f);   \
-          acc_to_frags(a, OUT[2 * t], OUT[2 * t + 1]);)
+          unsigned bits = 0u;                                                                 \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                    \
+            a[r] = fmaxf(acc[r] + b[r], 0.f); if (TRAIN) bits |= (a[r] > 0.f ? 1u : 0u) << r; } \
+          acc_to_frags(a, OUT[2 * t], OUT[2 * t + 1]);                                        \
+          if constexpr (TRAIN) {                                                              \
+            mk[((ML) * N::HT + t) * 64] = (unsigned short)bits;                               \
+            tile_store<false>(tiles, (PT) + t, OUT[2 * t], OUT[2 * t + 1]); })
       h8 r1[N::HK];
       h8 r2[N::HK];
       if constexpr (N::NCMID == 1) {
-        layer2_s<h8, N::HK, 1, N::HT>(sg, Wf, o.v[OFF_C0], nxt<N, OFF_CM0>(sg, Wf, o), feat, xn, AVC_F_RELU(OFF_CB0, r1));
-        layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_CM0], nxt<N, OFF_CH>(sg, Wf, o), r1, AVC_F_RELU(OFF_CBM0, r2));
+        layer2_s<h8, N::HK, 1, N::HT>(sg, Wf, o.v[OFF_C0], nxt<N, OFF_CM0>(sg, Wf, o), feat, xn, AVC_F_RELU(OFF_CB0, r1, L::P_R1, 0));
+        layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_CM0], nxt<N, OFF_CH>(sg, Wf, o), r1, AVC_F_RELU(OFF_CBM0, r2, L::P_R2, 1));
       } else {
-        layer2_s<h8, N::HK, 1, N::HT>(sg, Wf, o.v[OFF_C0], nxt<N, OFF_CH>(sg, Wf, o), feat, xn, AVC_F_RELU(OFF_CB0, r1));
+        layer2_s<h8, N::HK, 1, N::HT>(sg, Wf, o.v[OFF_C0], nxt<N, OFF_CH>(sg, Wf, o), feat, xn, AVC_F_RELU(OFF_CB0, r1, L::P_R1, 0));
 #pragma unroll
         for (int s = 0; s < N::HK; ++s) r2[s] = r1[s];
       }
@@ -231,7 +256,13 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
 }
 
 extern "C" long avc_fwd_scratch_bytes_per_wave(int net) {
-  return (long)(net == AVC_NET_FULL ? FwdScratch<NetFull>::S_KSTEPS : FwdScratch<NetSmall>::S_KSTEPS) * 1024;
+  return (long)(net == AVC_NET_FULL ? ScratchLayout<NetFull>::P_TILES : ScratchLayout<NetSmall>::P_TILES) * 2048;
+}
+extern "C" int avc_panel_tiles(int net) {
+  return net == AVC_NET_FULL ? PanelLayout<NetFull>::P_TILES : PanelLayout<NetSmall>::P_TILES;
+}
+extern "C" int avc_mask_u16_per_block(int net) {
+  return net == AVC_NET_FULL ? PanelLayout<NetFull>::MASK_U16 : PanelLayout<NetSmall>::MASK_U16;
 }
 
 static int grid_for(long npts, int waves_per_block, int max_blocks) {
@@ -283,14 +314,11 @@ extern "C" int avc_sdf_forward(int net, const float* pts, const float* rays_o, c
   return launch_sdf(net, ps, npts, wf16, tab, offs, sdf_out, slot, ld_out, stream);
 }
 
-extern "C" int avc_render_points_fwd(int net, const float* pts, const float* rays_o, const float* rays_d,
-                                     const float* z, int S, int ldz, float sample_dist, long npts, const void* wf16,
-                                     const float* tab, const int* offs, float* sdf_out, float* normal_out,
-                                     float* rgb_out, long max_waves, void* scratch, void* stream) {
-  if (npts <= 0) return 0;
-  if (!scratch) { avc_set_error("avc_render_points_fwd: scratch == NULL"); return 1; }
+template <bool TRAIN>
+static int launch_render(int net, PointSrc ps, long npts, const void* wf16, const float* tab, const int* offs, float* sdf_out,
+                         float* normal_out, float* rgb_out, long max_waves, void* store, void* masks, void* stream,
+                         const char* what) {
   if (check_tab(offs)) return 1;
-  PointSrc ps{pts, rays_o, rays_d, z, S, ldz, pts ? 0 : 1, sample_dist};
   AvcOffsets o;
   for (int k = 0; k < OFF_COUNT; ++k) o.v[k] = offs[k];
   long maxg = max_waves / FWD_WPB;
@@ -300,19 +328,41 @@ extern "C" int avc_render_points_fwd(int net, const float* pts, const float* ray
   hipStream_t s = (hipStream_t)stream;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)mlp_render_kernel<NetFull>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    hipFuncSetAttribute((const void*)mlp_render_kernel<NetSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    (void)hipFuncSetAttribute((const void*)mlp_render_kernel<NetFull, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    (void)hipFuncSetAttribute((const void*)mlp_render_kernel<NetSmall, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     attr_set = true;
   }
   if (net == AVC_NET_FULL)
-    hipLaunchKernelGGL((mlp_render_kernel<NetFull>), dim3(grid), dim3(64 * FWD_WPB), lds_bytes, s, ps, npts, (const h8*)wf16, tab, o,
-                       sdf_out, normal_out, rgb_out, (char*)scratch);
+    hipLaunchKernelGGL((mlp_render_kernel<NetFull, TRAIN>), dim3(grid), dim3(64 * FWD_WPB), lds_bytes, s, ps, npts, (const h8*)wf16, tab, o,
+                       sdf_out, normal_out, rgb_out, (char*)store, (unsigned short*)masks);
   else if (net == AVC_NET_SMALL)
-    hipLaunchKernelGGL((mlp_render_kernel<NetSmall>), dim3(grid), dim3(64 * FWD_WPB), lds_bytes, s, ps, npts, (const h8*)wf16, tab, o,
-                       sdf_out, normal_out, rgb_out, (char*)scratch);
+    hipLaunchKernelGGL((mlp_render_kernel<NetSmall, TRAIN>), dim3(grid), dim3(64 * FWD_WPB), lds_bytes, s, ps, npts, (const h8*)wf16, tab, o,
+                       sdf_out, normal_out, rgb_out, (char*)store, (unsigned short*)masks);
   else {
     avc_set_error("unknown net id");
     return 1;
   }
-  return avc_check_launch("avc_render_points_fwd");
+  return avc_check_launch(what);
+}
+
+extern "C" int avc_render_points_fwd(int net, const float* pts, const float* rays_o, const float* rays_d,
+                                     const float* z, int S, int ldz, float sample_dist, long npts, const void* wf16,
+                                     const float* tab, const int* offs, float* sdf_out, float* normal_out,
+                                     float* rgb_out, long max_waves, void* scratch, void* stream) {
+  if (npts <= 0) return 0;
+  if (!scratch) { avc_set_error("avc_render_points_fwd: scratch == NULL"); return 1; }
+  PointSrc ps{pts, rays_o, rays_d, z, S, ldz, pts ? 0 : 1, sample_dist};
+  return launch_render<false>(net, ps, npts, wf16, tab, offs, sdf_out, normal_out, rgb_out, max_waves, scratch, nullptr, stream,
+                              "avc_render_points_fwd");
+}
+
+extern "C" int avc_render_points_fwd_train(int net, const float* pts, const float* rays_o, const float* rays_d,
+                                           const float* z, int S, int ldz, float sample_dist, long npts, const void* wf16,
+                                           const float* tab, const int* offs, float* sdf_out, float* normal_out,
+                                           float* rgb_out, long max_waves, void* panels, void* masks, void* stream) {
+  if (npts <= 0) return 0;
+  if (!panels || !masks) { avc_set_error("avc_render_points_fwd_train: panels / masks == NULL"); return 1; }
+  PointSrc ps{pts, rays_o, rays_d, z, S, ldz, pts ? 0 : 1, sample_dist};
+  return launch_render<true>(net, ps, npts, wf16, tab, offs, sdf_out, normal_out, rgb_out, max_waves, panels, masks, stream,
+                             "avc_render_points_fwd_train");
 }

@@ -75,8 +75,11 @@ class Engine:
     prof_events = []
     WG_NSPLIT = 256               # split-K workgroups per weight-gradient pair (one per CU; 512 and 1024 measured 1.5 % / 6 % slower: partial-slab traffic)
     MAX_FWD_WAVES = 2048          # persistent grid of avc_render_points_fwd: 256 CUs x one 8-wave workgroup
-    MAX_BWD_WAVES = 2048          # 256 CUs x 4 wavefronts (one per SIMD: the backward kernel uses the full RF)
-    # weight-gradient operand panels per chunk of points (capped at 70 % of the free HBM); AVC_PANEL_GIB overrides (tuning aid)
+    MAX_BWD_WAVES = 2048          # 256 CUs x one 8-wave workgroup
+    # operand panels (11.25 KiB per point for the full nets) per chunk of rays, capped at 70 % of the free HBM.  When one
+    # chunk holds the whole ray set (512^2 x 64 spp = 177 GiB: fits the 288 GB of an MI355X) the forward pass runs ONCE and its
+    # panels live until the backward pass; otherwise the backward re-runs the training forward chunk by chunk (the price of a
+    # ray set whose operands do not fit).  AVC_PANEL_GIB overrides the budget (tuning / test aid)
     PANEL_BYTES_BUDGET = int(os.environ.get("AVC_PANEL_GIB", "192")) << 30
 
     def __init__(self, spec: PK.NetSpec, device):
@@ -88,17 +91,20 @@ class Engine:
         self.dl = _DevLayout.get(spec, device)
         self.net = spec.net_id
         assert self.lib.avc_num_offsets() == PK.OFF_COUNT
-        self.ptiles = self.lib.avc_bwd_panel_tiles(self.net)
-        assert self.ptiles == self.dl.lay.panel["TILES"], "panel layout mismatch between packing.py and avc_mlp_bwd.hip"
+        self.ptiles = self.lib.avc_panel_tiles(self.net)
+        assert self.ptiles == self.dl.lay.panel["TILES"], "panel layout mismatch between packing.py and csrc/avc_mlp.h"
+        self.mask_u16 = self.lib.avc_mask_u16_per_block(self.net)
         self.fwd_scr_bytes = self.lib.avc_fwd_scratch_bytes_per_wave(self.net)
         self._fwd_scratch = None
         self._panels = None
         self._partials = None
         self._bpartials = None
-        self._pairs_host = np.ascontiguousarray(np.asarray(self.dl.lay.pairs, dtype=np.int32).reshape(-1, 6))
+        self._masks = None
+        self._pairs_host = np.ascontiguousarray(np.asarray(self.dl.lay.pairs, dtype=np.int32).reshape(-1, 8))
         self._sdf_bias0 = int(self.dl.lay.pbase["sdf.b%d" % (spec.NMID + 2)])   # flat index of bias[0] of the last SDF layer
         self._packed_key = None
         self._packed = None
+        self._panel_owner = None      # token of the RenderCoreFn.forward whose operand panels the buffers hold
 
     @classmethod
     def for_networks(cls, sdf_net, col_net):
@@ -134,12 +140,24 @@ class Engine:
         return Packed(self.dl, flatP)
 
     def _bufs(self, nblk_chunk):
-        need = nblk_chunk * self.ptiles * 2048
+        """panels + ReLU masks for `nblk_chunk` 32-point blocks (+ 1 sink block for the wavefronts past the end)"""
+        need = (nblk_chunk + 1) * self.ptiles * 2048
         if self._panels is None or self._panels.numel() < need:
             self._panels = None          # release the old buffer BEFORE the larger one is allocated (peak = need, not have + need)
             torch.cuda.empty_cache()
             self._panels = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._panels
+        needm = (nblk_chunk + 1) * self.mask_u16
+        if self._masks is None or self._masks.numel() < needm:
+            self._masks = torch.empty(needm, dtype=torch.int16, device=self.device)
+        return self._panels, self._masks
+
+    def rays_per_chunk(self, R, S):
+        """how many rays' operand panels fit the budget (see PANEL_BYTES_BUDGET)"""
+        have = self._panels.numel() if self._panels is not None else 0
+        # 70 % of what is free once the current buffer is given back (it is released before a larger one is allocated)
+        budget = max(min(self.PANEL_BYTES_BUDGET, (torch.cuda.mem_get_info(self.device)[0] + have) * 7 // 10), 1 << 28)
+        max_blocks = max(1, budget // (self.ptiles * 2048) - 1)
+        return max(1, min(R, int(max_blocks * 32 // S) - 1))
 
     # ------------------------------------------------------------------ forward launches
     def sdf_rays(self, pk: Packed, rays_o, rays_d, z, sdf_out=None, slot=None, ld_out=0):
@@ -186,6 +204,25 @@ class Engine:
                                                    L.stream()), "avc_render_points_fwd")
         return sdf, nrm, rgb
 
+    def points_fwd_train(self, pk: Packed, rays_o, rays_d, z, sample_dist, r0=0, r1=None, out=None):
+        """the differentiable forward of rays r0:r1: outputs + operand panels / masks of those rays' blocks (engine buffers)"""
+        R, S = z.shape
+        r1 = R if r1 is None else r1
+        if out is None:
+            out = (torch.empty(R, S, device=self.device, dtype=torch.float32), torch.empty(R, S, 3, device=self.device, dtype=torch.float32),
+                   torch.empty(R, S, 6, device=self.device, dtype=torch.float32))
+        sdf, nrm, rgb = out
+        npts = (r1 - r0) * S
+        panels, masks = self._bufs((npts + 31) // 32)
+        esz = 4
+        with Engine._Timed("avc_render_points_fwd_train", npts):
+            L.check(self.lib.avc_render_points_fwd_train(
+                self.net, None, rays_o.data_ptr() + r0 * 3 * esz, rays_d.data_ptr() + r0 * 3 * esz,
+                z.data_ptr() + r0 * z.stride(0) * esz, S, z.stride(0), float(sample_dist), npts, L.ptr(pk.w_f16), L.ptr(pk.tab),
+                self.dl.offsets, sdf.data_ptr() + r0 * S * esz, nrm.data_ptr() + r0 * S * 3 * esz, rgb.data_ptr() + r0 * S * 6 * esz,
+                self.MAX_FWD_WAVES, L.ptr(panels), L.ptr(masks), L.stream()), "avc_render_points_fwd_train")
+        return out
+
     def composite_fwd(self, sdf, nrm, rgb, z, rays_o, rays_d, inv_s, sample_dist, cos_anneal, bg, bg_mode):
         R, S = z.shape
         dev, f32 = self.device, torch.float32
@@ -218,19 +255,15 @@ class Engine:
         return d_sdf, d_n, d_rgb, d_inv
 
     # ------------------------------------------------------------------ backward of the point MLP
-    def points_bwd(self, pk: Packed, rays_o, rays_d, z, sample_dist, d_sdf, d_n, d_rgb):
-        """returns the flat dense gradient [nparam] (fp32)."""
+    def points_bwd(self, pk: Packed, rays_o, rays_d, z, sample_dist, d_sdf, d_n, d_rgb, rgb, panels_valid=False):
+        """returns the flat dense gradient [nparam] (fp32).  `rgb` = the forward's colours.  panels_valid: the engine buffers
+        still hold the operand panels of exactly this ray set (single chunk, nothing rendered since) -- otherwise the
+        training forward is re-run per chunk."""
         lay = self.dl.lay
         R, S = z.shape
-        per_ray_blocks = S / 32.0
-        have = self._panels.numel() if self._panels is not None else 0
-        # 70 % of what is free once the current buffer is given back (it is released before a larger one is allocated)
-        budget = max(min(self.PANEL_BYTES_BUDGET, (torch.cuda.mem_get_info(self.device)[0] + have) * 7 // 10), 1 << 28)
-        max_blocks = max(1, budget // (self.ptiles * 2048))
-        rays_per_chunk = max(1, int(max_blocks / per_ray_blocks) - 1)
-        rays_per_chunk = min(rays_per_chunk, R)
-        nblk_max = (rays_per_chunk * S + 31) // 32
-        panels = self._bufs(nblk_max)
+        rays_per_chunk = self.rays_per_chunk(R, S)
+        if rays_per_chunk < R:
+            panels_valid = False
         gout = torch.zeros(lay.gout_size, device=self.device, dtype=torch.float32)
         gbias = torch.zeros(max(lay.gbias_size, 1), device=self.device, dtype=torch.float32)
         nsplit = self.WG_NSPLIT
@@ -239,16 +272,23 @@ class Engine:
             self._bpartials = torch.empty(nsplit, max(lay.gbias_size, 1), device=self.device, dtype=torch.float32)
         st = L.stream()
         esz = 4
+        scratch_out = None
         for r0 in range(0, R, rays_per_chunk):
             r1 = min(R, r0 + rays_per_chunk)
             npts = (r1 - r0) * S
             nblk = (npts + 31) // 32
+            if not panels_valid:
+                if scratch_out is None:   # outputs of the re-run are not needed (identical to the first pass)
+                    scratch_out = (torch.empty(R, S, device=self.device), torch.empty(R, S, 3, device=self.device),
+                                   torch.empty(R, S, 6, device=self.device))
+                self.points_fwd_train(pk, rays_o, rays_d, z, sample_dist, r0, r1, out=scratch_out)
+            panels, masks = self._bufs(nblk)
             with Engine._Timed("avc_render_points_bwd", npts):
                 L.check(self.lib.avc_render_points_bwd(
                     self.net, None, rays_o.data_ptr() + r0 * 3 * esz, rays_d.data_ptr() + r0 * 3 * esz,
-                    z.data_ptr() + r0 * z.stride(0) * esz, S, z.stride(0), float(sample_dist), npts, L.ptr(pk.w_f16),
-                    L.ptr(pk.w_bf16), L.ptr(pk.tab), self.dl.offsets, d_sdf.data_ptr() + r0 * S * esz,
-                    d_n.data_ptr() + r0 * S * 3 * esz, d_rgb.data_ptr() + r0 * S * 6 * esz, L.ptr(panels),
+                    z.data_ptr() + r0 * z.stride(0) * esz, S, z.stride(0), float(sample_dist), npts, L.ptr(pk.w_bf16), L.ptr(pk.tab),
+                    self.dl.offsets, d_sdf.data_ptr() + r0 * S * esz, d_n.data_ptr() + r0 * S * 3 * esz,
+                    d_rgb.data_ptr() + r0 * S * 6 * esz, rgb.data_ptr() + r0 * S * 6 * esz, L.ptr(panels), L.ptr(masks),
                     self.MAX_BWD_WAVES, st), "avc_render_points_bwd")
             ns = max(1, min(nblk, nsplit))
             with Engine._Timed("avc_weight_grad(all pairs)", npts):
@@ -257,6 +297,7 @@ class Engine:
                                                      self._partials.stride(0), self._bpartials.stride(0), st), "avc_weight_grad_all")
                 gout += self._partials[:ns].sum(0)
                 gbias += self._bpartials[:ns].sum(0)
+        self._panel_owner = None
         grad = torch.zeros(lay.nparam, device=self.device, dtype=torch.float32)
         grad.index_add_(0, self.dl.un_tgt, gout[self.dl.un_src] * self.dl.un_scale)
         if lay.gbias_size:
@@ -275,7 +316,15 @@ class RenderCoreFn(torch.autograd.Function):
     def forward(ctx, flatP, inv_s, eng, rays_o, rays_d, z_vals, sample_dist, cos_anneal, bg, bg_mode):
         pk = eng.pack(flatP)
         inv_s_d = inv_s.detach().float().contiguous()
-        sdf, nrm, rgb = eng.points_fwd(pk, rays_o, rays_d, z_vals, sample_dist)
+        R, S = z_vals.shape
+        needs_grad = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])   # (grad mode itself is off inside forward)
+        ctx.panel_token = None
+        if needs_grad and eng.rays_per_chunk(R, S) >= R:
+            # the whole ray set's operand panels fit: the forward runs once and leaves them for the backward pass
+            sdf, nrm, rgb = eng.points_fwd_train(pk, rays_o, rays_d, z_vals, sample_dist)
+            ctx.panel_token = eng._panel_owner = object()
+        else:
+            sdf, nrm, rgb = eng.points_fwd(pk, rays_o, rays_d, z_vals, sample_dist)
         color, extra, weights, cdf, mid_z, inside, eik = eng.composite_fwd(
             sdf, nrm, rgb, z_vals, rays_o, rays_d, inv_s_d, sample_dist, cos_anneal, bg, bg_mode)
         eik_den = eik[:, 1].sum() + 1e-5
@@ -304,5 +353,6 @@ class RenderCoreFn(torch.autograd.Function):
         eik_scale = (d_gerr.float() / eik_den).reshape(1).contiguous()
         d_sdf, d_n, d_rgb, d_inv = eng.composite_bwd(sdf, nrm, rgb, z_vals, rays_o, rays_d, inv_s_d, sample_dist,
                                                      cos_anneal, bg, bg_mode, d_color, d_extra, d_weights, d_nrm, eik_scale)
-        grad = eng.points_bwd(pk, rays_o, rays_d, z_vals, sample_dist, d_sdf, d_n, d_rgb)
+        valid = ctx.panel_token is not None and eng._panel_owner is ctx.panel_token
+        grad = eng.points_bwd(pk, rays_o, rays_d, z_vals, sample_dist, d_sdf, d_n, d_rgb, rgb, panels_valid=valid)
         return grad, d_inv.sum().reshape(1), None, None, None, None, None, None, None, None

@@ -23,8 +23,10 @@ _SIGS = {
     "avc_composite_fwd": (c_int, [P, P, P, P, P, P, c_int, c_int, P, c_float, c_float, P, c_int, P, P, P, P, P, P, P, P]),
     "avc_composite_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, P, c_float, c_float, P, c_int, P, P, P, P, P, P, P,
                                   P, P, P]),
-    "avc_render_points_bwd": (c_int, [c_int, P, P, P, P, c_int, c_int, c_float, c_long, P, P, P, P, P, P, P, P, c_long,
-                                      P]),
+    "avc_render_points_fwd_train": (c_int, [c_int, P, P, P, P, c_int, c_int, c_float, c_long, P, P, P, P, P, P, c_long, P, P, P]),
+    "avc_panel_tiles": (c_int, [c_int]),
+    "avc_mask_u16_per_block": (c_int, [c_int]),
+    "avc_render_points_bwd": (c_int, [c_int, P, P, P, P, c_int, c_int, c_float, c_long, P, P, P, P, P, P, P, P, P, c_long, P]),
     "avc_mc_classify": (c_int, [P, c_int, c_int, c_int, c_float, P, P, P, P]),
     "avc_mc_emit": (c_int, [P, c_int, c_int, c_int, c_float, P, P, P, P, P, P, P, P, P]),
     "avc_text_attention_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
@@ -33,7 +35,6 @@ _SIGS = {
     "avc_vit_attention_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "avc_vit_attention_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "avc_probe_mfma": (c_int, [P, P, P, P, P, P, P]),
-    "avc_weight_grad": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_long, P, P, c_int, c_int, c_int, P]),
     "avc_rasterize_faces": (c_int, [P, P, c_int, c_int, c_float, c_float, P, P]),
     "avc_weight_grad_all": (c_int, [P, c_int, c_int, P, c_long, P, P, c_int, c_int, c_int, P]),
 }

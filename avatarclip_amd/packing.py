@@ -178,7 +178,7 @@ class Layout:
     scale32: np.ndarray
     offsets: np.ndarray
     panel: Dict[str, int]
-    pairs: List[Tuple[int, int, int, int, int, int]]   # (pa, ta, pb, tb, out_off, bias_off)
+    pairs: List[Tuple[int, int, int, int, int, int, int, int]]   # (pa, ta, pb, tb, out_off, bias_off, type_a, type_b); type 0 = f16 tile, 1 = bf16 tile
     gout_size: int
     gbias_size: int
     un_src: np.ndarray
@@ -322,7 +322,7 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
     table("OFF_CBH", bias_tab("col.bh", 6, 1))
     offsets[OFF["OFF_TAB_END"]] = cur32[0]
 
-    # ---------------- panel layout (mirror of BwdLayout in csrc/avc_mlp_bwd.hip)
+    # ---------------- panel layout (mirror of PanelLayout in csrc/avc_mlp.h)
     P = {}
     c = 0
     for name, nt in [("H0", 2), ("GB0", 2), ("H1", HT), ("HM", NMID * HT), ("HS", ST), ("GBH1", HT),
@@ -332,6 +332,13 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
         P[name] = c
         c += nt
     P["TILES"] = c
+    # forward-type operands are written by the forward kernel as f16 tiles, gradient-type operands by the backward kernel as bf16
+    F16_PANELS = ("H0", "H1", "HM", "HS", "GA1", "GAM", "GAS", "FEAT", "XN", "R1", "R2")
+    bounds = sorted((v, k) for k, v in P.items() if k != "TILES")
+
+    def panel_type(tile):
+        name = [k for v, k in bounds if v <= tile][-1]
+        return 0 if name in F16_PANELS else 1
 
     # ---------------- weight-gradient pairs and the map of their outputs back to the dense gradient
     pairs, un_src, un_tgt, un_scale, ub_src, ub_tgt = [], [], [], [], [], []
@@ -383,7 +390,8 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
                     un_src.append(src)
                     un_tgt.append(pbase[wname] + rws[ok] * ld + col)
                     un_scale.append(np.full(len(src), scale, np.float32))
-        pairs.append((pa, ta, pb, tb, out_off, bias_off))
+        assert len({panel_type(pa + t) for t in range(ta)}) == 1 and len({panel_type(pb + t) for t in range(tb)}) == 1
+        pairs.append((pa, ta, pb, tb, out_off, bias_off, panel_type(pa), panel_type(pb)))
         gout[0] += ta * tb * 64 * 16
 
     # SDF layer 0

@@ -71,27 +71,40 @@ int avc_composite_bwd(const float* sdf, const float* normal, const float* rgb, c
                       const float* d_weights, const float* d_normal_up, const float* eik_scale, float* d_sdf,
                       float* d_normal, float* d_rgb, float* d_inv_s, void* stream);
 
-/* Backward of avc_render_points_fwd wrt every dense weight (autograd incl. the double backward of
- * SDFNetwork.gradient, fields.py:96-107; main.py:537).  Recomputes the forward, runs the second-order and the
- * reverse sweep and writes the bf16 operand panels of every weight-gradient product to `panels`
- * (avc_bwd_panel_tiles(net) tiles of 2 KiB per 32-point block); avc_weight_grad then contracts them over the
- * points.  The kernel keeps no other state in memory: what a later sweep needs again it reads back from the panels.
- * max_waves bounds the resident grid (persistent workgroups of 8 wavefronts). */
-int avc_bwd_panel_tiles(int net);
-int avc_render_points_bwd(int net, const float* pts, const float* rays_o, const float* rays_d, const float* z,
-                          int S, int ldz, float sample_dist, long npts, const void* wf16, const void* wbf16,
-                          const float* tab, const int* offs /* host */, const float* d_sdf, const float* d_normal,
-                          const float* d_rgb, void* panels, long max_waves, void* stream);
+/* The differentiable forward of render_core (renderer.py:221-232, once per iteration as in the reference): the same outputs
+ * as avc_render_points_fwd, plus everything the backward pass and the weight-gradient products need from the forward pass,
+ * written to the OPERAND PANELS of each 32-point block: avc_panel_tiles(net) tiles of 2 KiB per block, each tile = the two
+ * 16-bit B-operand fragments [k-step][lane = point + 32 half][8 features] of 32 features x 32 points (f16 for what this
+ * kernel writes: PE values, h_l, g_a,l, feature vector, [x,n], r1, r2), and the ReLU masks of r1 / r2
+ * (avc_mask_u16_per_block(net) x 16 bits per block).  Both buffers need (nblk + 1) blocks, nblk = ceil(npts / 32): the
+ * last block is a sink for wavefronts past the end. */
+int avc_panel_tiles(int net);
+int avc_mask_u16_per_block(int net);
+int avc_render_points_fwd_train(int net, const float* pts, const float* rays_o, const float* rays_d, const float* z,
+                                int S, int ldz, float sample_dist, long npts, const void* wf16, const float* tab,
+                                const int* offs /* host */, float* sdf_out, float* normal_out, float* rgb_out,
+                                long max_waves, void* panels, void* masks, void* stream);
 
-/* partial[split][ta,tb,64,16] = sum over the split's share of `nblk` 32-point blocks of A-panel tile (pa+ta) x B-panel
- * tile (pb+tb), K = points; lane (n,h), reg r of tile (ta,tb) is dW[32 ta + (r&3)+8(r>>2)+4h][32 tb + n].
- * bias_partial[split][32 ta] (may be NULL) receives sum_points A[:, 32 ta + n].  nsplit = split-K factor = grid size;
- * split s writes its slab at partial + s*out_stride (bias_partial + s*bias_stride), floats; the caller sums the slabs. */
-int avc_weight_grad(const void* panels, int ptiles, int pa, int ta, int pb, int tb, long nblk, float* partial,
-                    float* bias_partial, int nsplit, int out_stride, int bias_stride, void* stream);
-/* all products of one backward pass in one launch.  pairs (host) = npairs x {pa, ta, pb, tb, out_off, bias_off}: pair i
- * writes its tiles at partial + out_off (floats) of every split's slab and its bias sums at bias_partial + bias_off
- * (bias_off < 0: none).  Same arithmetic as npairs calls of avc_weight_grad. */
+/* Backward of avc_render_points_fwd_train wrt every dense weight (autograd incl. the double backward of
+ * SDFNetwork.gradient, fields.py:96-107; main.py:537).  Recomputes nothing of the forward: reads h_l, g_a,l, the masks and
+ * the colours (rgb_fwd = the forward's rgb_out) back, runs the colour backward, the second-order sweep and the reverse sweep
+ * (bf16 operands) and adds the gradient-type operand tiles (gbar_h, abar, delta, ybar; bf16) to the same panels;
+ * avc_weight_grad_all then contracts the panels over the points.  max_waves bounds the resident grid (persistent
+ * workgroups of 8 wavefronts). */
+int avc_bwd_panel_tiles(int net);   /* == avc_panel_tiles */
+int avc_render_points_bwd(int net, const float* pts, const float* rays_o, const float* rays_d, const float* z,
+                          int S, int ldz, float sample_dist, long npts, const void* wbf16, const float* tab,
+                          const int* offs /* host */, const float* d_sdf, const float* d_normal, const float* d_rgb,
+                          const float* rgb_fwd, void* panels, const void* masks, long max_waves, void* stream);
+
+/* Every weight-gradient product of one backward pass in one launch.  pairs (host) = npairs x {pa, ta, pb, tb, out_off,
+ * bias_off, type_a, type_b}: pair i contracts A tiles pa .. pa+ta-1 (ta <= 8) with B tiles pb .. pb+tb-1 (tb <= 9) over the
+ * points of `nblk` blocks; type = 0 (f16 tile) | 1 (bf16 tile).  The fragment-layout tiles are transposed to
+ * feature-major on the matrix core as they are loaded (two MFMAs against a 0/1 selection fragment per tile) and contracted
+ * in bf16 with fp32 accumulation.  partial[split][out_off + ((ta_i * tb + tb_j) * 64 + lane) * 16 + r] = element
+ * dW[32 ta_i + (r&3)+8(r>>2)+4h][32 tb_j + n] of lane (n,h); bias_partial[split][bias_off + 32 ta_i + n] = sum_points
+ * A[:, 32 ta_i + n] (bias_off < 0: none).  nsplit = split-K factor (grid x); split s writes its slab at
+ * partial + s*out_stride (bias_partial + s*bias_stride), floats; the caller sums the slabs (no atomics). */
 int avc_weight_grad_all(const void* panels, int ptiles, int npairs, const int* pairs /* host */, long nblk, float* partial,
                         float* bias_partial, int nsplit, int out_stride, int bias_stride, void* stream);
 

@@ -24,6 +24,8 @@ for npts in sizes:
     ms_sdf = t(lambda: eng.sdf_rays(pk, ro, rd, z))
     ms_fwd = t(lambda: eng.points_fwd(pk, ro, rd, z, 2 / 32))
     dsdf = torch.randn(R, 64, device=dev); dn = torch.randn(R, 64, 3, device=dev) * 0.1; drgb = torch.randn(R, 64, 6, device=dev) * 0.1
-    ms_bwd = t(lambda: eng.points_bwd(pk, ro, rd, z, 2 / 32, dsdf, dn, drgb), reps=3)
-    print("npts %8d  points_bwd+weight_grad %8.3f ms" % (npts, ms_bwd), flush=True)
+    ms_fwt = t(lambda: eng.points_fwd_train(pk, ro, rd, z, 2 / 32))
+    _, _, rgbf = eng.points_fwd_train(pk, ro, rd, z, 2 / 32)
+    ms_bwd = t(lambda: eng.points_bwd(pk, ro, rd, z, 2 / 32, dsdf, dn, drgb, rgbf, panels_valid=True), reps=3)
+    print("npts %8d  points_fwd_train %8.3f ms (%.1f TF/s)   points_bwd+weight_grad %8.3f ms" % (npts, ms_fwt, npts * 1186816 / ms_fwt / 1e9, ms_bwd), flush=True)
     print("npts %8d  sdf-only %8.3f ms (%.1f TF/s)   points_fwd %8.3f ms (%.1f TF/s)" % (npts, ms_sdf, npts * 393728 / ms_sdf / 1e9, ms_fwd, npts * 1186816 / ms_fwd / 1e9), flush=True)

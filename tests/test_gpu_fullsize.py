@@ -89,8 +89,11 @@ def test_fullsize_gradient_linearity_and_chunk_invariance():
     d_sdf = torch.randn(R, S, device=dev, generator=g) * 1e-3
     d_n = torch.randn(R, S, 3, device=dev, generator=g) * 1e-3
     d_rgb = torch.randn(R, S, 6, device=dev, generator=g) * 1e-3
-    g1 = eng.points_bwd(pk, ro, rd, z, 2.0 / 32, d_sdf, d_n, d_rgb)
-    g2 = eng.points_bwd(pk, ro, rd, z, 2.0 / 32, 2 * d_sdf, 2 * d_n, 2 * d_rgb)
+    # the training forward leaves the operand panels of the whole view (177 GiB) in the engine buffers; the first backward uses
+    # them, the second one finds them still there (the backward only ADDS the gradient-type tiles)
+    _, _, rgb = eng.points_fwd_train(pk, ro, rd, z, 2.0 / 32)
+    g1 = eng.points_bwd(pk, ro, rd, z, 2.0 / 32, d_sdf, d_n, d_rgb, rgb, panels_valid=True)
+    g2 = eng.points_bwd(pk, ro, rd, z, 2.0 / 32, 2 * d_sdf, 2 * d_n, 2 * d_rgb, rgb, panels_valid=True)
     torch.cuda.synchronize()
     assert torch.isfinite(g1).all() and g1.abs().max() > 0
     # every kernel is exactly linear under power-of-two scaling; the final scatter of the (i)/(ii) products into the dense
@@ -100,8 +103,8 @@ def test_fullsize_gradient_linearity_and_chunk_invariance():
     assert lin < 1e-7
     old = Engine.PANEL_BYTES_BUDGET
     try:
-        Engine.PANEL_BYTES_BUDGET = 3 << 30      # many more, smaller launches
-        g3 = eng.points_bwd(pk, ro, rd, z, 2.0 / 32, d_sdf, d_n, d_rgb)
+        Engine.PANEL_BYTES_BUDGET = 3 << 30      # many more, smaller launches: the backward re-runs the training forward per chunk
+        g3 = eng.points_bwd(pk, ro, rd, z, 2.0 / 32, d_sdf, d_n, d_rgb, rgb)
     finally:
         Engine.PANEL_BYTES_BUDGET = old
     torch.cuda.synchronize()

@@ -365,7 +365,7 @@ def weight_grad(lay: PK.Layout, panel_blocks):
     """mirrors avc_weight_grad over a list of panel dicts; returns (gout, gbias)."""
     gout = np.zeros(lay.gout_size)
     gbias = np.zeros(max(lay.gbias_size, 1))
-    for (pa, ta, pb, tb, out_off, bias_off) in lay.pairs:
+    for (pa, ta, pb, tb, out_off, bias_off, _ta, _tb) in lay.pairs:
         for t_a in range(ta):
             for t_b in range(tb):
                 acc = np.zeros((64, 16))

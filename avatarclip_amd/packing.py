@@ -325,20 +325,20 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
     # ---------------- panel layout (mirror of PanelLayout in csrc/avc_mlp.h)
     P = {}
     c = 0
+    # forward-type operands are written by the forward kernel as f16 tiles, gradient-type operands by the backward kernel as bf16
+    F16_PANELS = ("H0", "H1", "HM", "HS", "GA1", "GAM", "GAS", "FEAT", "XN", "R1", "R2")
+    tile_type = []
     for name, nt in [("H0", 2), ("GB0", 2), ("H1", HT), ("HM", NMID * HT), ("HS", ST), ("GBH1", HT),
                      ("GBHM", NMID * HT), ("GBHS", ST), ("GA1", HT), ("GAM", NMID * HT), ("GAS", ST), ("AB1", HT),
                      ("ABM", NMID * HT), ("ABS", ST), ("DFEAT", HT), ("SDF", 1), ("ONE", 1), ("FEAT", HT), ("XN", 1),
                      ("R1", HT), ("R2", NCMID * HT), ("D1", HT), ("D2", NCMID * HT), ("DO", 1)]:
         P[name] = c
         c += nt
+        tile_type += [0 if name in F16_PANELS else 1] * nt
     P["TILES"] = c
-    # forward-type operands are written by the forward kernel as f16 tiles, gradient-type operands by the backward kernel as bf16
-    F16_PANELS = ("H0", "H1", "HM", "HS", "GA1", "GAM", "GAS", "FEAT", "XN", "R1", "R2")
-    bounds = sorted((v, k) for k, v in P.items() if k != "TILES")
 
     def panel_type(tile):
-        name = [k for v, k in bounds if v <= tile][-1]
-        return 0 if name in F16_PANELS else 1
+        return tile_type[tile]
 
     # ---------------- weight-gradient pairs and the map of their outputs back to the dense gradient
     pairs, un_src, un_tgt, un_scale, ub_src, ub_tgt = [], [], [], [], [], []

@@ -96,13 +96,19 @@ __device__ __forceinline__ void dephase(const ST& st) {
   }
 }
 #define AVC_EPI(...) [&](int t, const facc& acc) __attribute__((always_inline)) { __VA_ARGS__ }
+// Optional hook run once per layer right AFTER the barrier of its first weight group: the place for streaming stores of the
+// previous layer's output tiles (still live as this layer's input).  hipcc drains vmcnt(0) before every group barrier while an
+// LDS-DMA is pending, and stores count on vmcnt: a store issued in an epilogue right before a barrier stalls the whole
+// workgroup for an HBM write round trip; issued right after one it has a group of MFMA work (~2 us) to complete under.
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+#define AVC_HOOK(...) [&]() __attribute__((always_inline)) { __VA_ARGS__ }
 
 #ifndef AVC_PAIR
 #define AVC_PAIR 0   // 1: two output tiles per MFMA stream (independent accumulators), 0: one dependent chain per tile
 #endif
-template <typename V, int KS, int NT, class ST, typename Epi>
+template <typename V, int KS, int NT, class ST, typename Epi, typename Hook = NoHook>
 __device__ __forceinline__ void layer_s(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&in)[KS],
-                                        Epi&& epi) {
+                                        Epi&& epi, Hook&& hook = NoHook{}) {
   constexpr int G = ST::template group<KS>();
   constexpr int NG = (NT + G - 1) / G;
   facc prev0, prev1;
@@ -118,6 +124,7 @@ __device__ __forceinline__ void layer_s(ST& st, const V* __restrict__ blob, int 
     } else {
       stage_issue(st, after, st.par ^ 1);
     }
+    if (g == 0) hook();
     dephase(st);
 #pragma unroll
     for (int j = 0; j < G; j += (AVC_PAIR ? 2 : 1)) {
@@ -156,9 +163,9 @@ __device__ __forceinline__ void layer_s(ST& st, const V* __restrict__ blob, int 
 // DEEP = false: pre(t-1) goes out before the chain of tile t (one chain of head start, one load set live);
 // DEEP = true:  pre(t) goes out before the chain of tile t (two chains + one epilogue of head start, two sets live) --
 //               measured slower for the three-array loads of the reverse sweep (register pressure), see DESIGN.md 5.
-template <bool AVC_PRE_DEEP, typename V, int KS, int NT, class ST, typename Pre, typename Epi>
+template <bool AVC_PRE_DEEP, typename V, int KS, int NT, class ST, typename Pre, typename Epi, typename Hook>
 __device__ __forceinline__ void layer_sq_(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&in)[KS],
-                                         Pre&& pre, Epi&& epi) {
+                                         Pre&& pre, Epi&& epi, Hook&& hook) {
   constexpr int G = ST::template group<KS>();
   constexpr int NG = (NT + G - 1) / G;
   facc prev;
@@ -174,6 +181,7 @@ __device__ __forceinline__ void layer_sq_(ST& st, const V* __restrict__ blob, in
     } else {
       stage_issue(st, after, st.par ^ 1);
     }
+    if (g == 0) hook();
 #pragma unroll
     for (int j = 0; j < G; ++j) {
       const int t = g * G + j;
@@ -198,19 +206,19 @@ __device__ __forceinline__ void layer_sq_(ST& st, const V* __restrict__ blob, in
   epi(NT - 1, prev, dprev);
   __builtin_amdgcn_sched_barrier(0);
 }
-template <typename V, int KS, int NT, class ST, typename Pre, typename Epi>
+template <typename V, int KS, int NT, class ST, typename Pre, typename Epi, typename Hook = NoHook>
 __device__ __forceinline__ void layer_sq(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&in)[KS],
-                                         Pre&& pre, Epi&& epi) {
-  layer_sq_<false, V, KS, NT>(st, blob, offw, after, in, pre, epi);
+                                         Pre&& pre, Epi&& epi, Hook&& hook = NoHook{}) {
+  layer_sq_<false, V, KS, NT>(st, blob, offw, after, in, pre, epi, hook);
 }
-template <typename V, int KS, int NT, class ST, typename Pre, typename Epi>
+template <typename V, int KS, int NT, class ST, typename Pre, typename Epi, typename Hook = NoHook>
 __device__ __forceinline__ void layer_sqd(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&in)[KS],
-                                          Pre&& pre, Epi&& epi) {
-  layer_sq_<AVC_DEEP_PF1 != 0, V, KS, NT>(st, blob, offw, after, in, pre, epi);
+                                          Pre&& pre, Epi&& epi, Hook&& hook = NoHook{}) {
+  layer_sq_<AVC_DEEP_PF1 != 0, V, KS, NT>(st, blob, offw, after, in, pre, epi, hook);
 }
-template <typename V, int KA, int KB, int NT, class ST, typename Epi>
+template <typename V, int KA, int KB, int NT, class ST, typename Epi, typename Hook = NoHook>
 __device__ __forceinline__ void layer2_s(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&ina)[KA],
-                                         const V (&inb)[KB], Epi&& epi) {
+                                         const V (&inb)[KB], Epi&& epi, Hook&& hook = NoHook{}) {
   constexpr int KS = KA + KB;
   constexpr int G = ST::template group<KS>();
   constexpr int NG = (NT + G - 1) / G;
@@ -226,6 +234,7 @@ __device__ __forceinline__ void layer2_s(ST& st, const V* __restrict__ blob, int
     } else {
       stage_issue(st, after, st.par ^ 1);
     }
+    if (g == 0) hook();
     dephase(st);
 #pragma unroll
     for (int j = 0; j < G; ++j) {
@@ -323,6 +332,12 @@ __device__ __forceinline__ void tile_store(const PanelPtr& pp, int tile, const V
     AVC_NT_STORE(f0, &p[0]);
     AVC_NT_STORE(f1, &p[64]);
   }
+}
+// all tiles of one activation (fragment array `f`, 2 per tile) in one go -- what the hooks above issue
+template <bool KEEP, int NT, typename V, int KS>
+__device__ __forceinline__ void tiles_store(const PanelPtr& pp, int tile0, const V (&f)[KS]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) tile_store<KEEP>(pp, tile0 + t, f[2 * t], f[2 * t + 1]);
 }
 template <typename V> struct FragPair { V a0, a1; };     // the two k-step fragments of a panel tile
 template <bool NT, typename V>

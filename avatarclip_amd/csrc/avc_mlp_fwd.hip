@@ -9,6 +9,27 @@
 #ifndef FWD_G
 #define FWD_G 4
 #endif
+// timing ablations of the training forward (results are garbage): which of its extra stores cost what
+#ifdef AVC_ABL_NOMASK
+constexpr bool ABL_NOMASK = true;
+#else
+constexpr bool ABL_NOMASK = false;
+#endif
+#ifdef AVC_ABL_NORSTORE
+constexpr bool ABL_NORSTORE = true;
+#else
+constexpr bool ABL_NORSTORE = false;
+#endif
+#ifdef AVC_ABL_NOGASTORE
+constexpr bool ABL_NOGASTORE = true;
+#else
+constexpr bool ABL_NOGASTORE = false;
+#endif
+#ifdef AVC_ABL_NOMISC
+constexpr bool ABL_NOMISC = true;
+#else
+constexpr bool ABL_NOMISC = false;
+#endif
 #include "../../include/avc.h"
 
 template <class N>
@@ -106,45 +127,46 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
       }
       h8 pef[3];
       pe_to_frags_f16(pe, x, h, pef);
-      if constexpr (TRAIN) {
-        h8 zf;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) zf[j] = (_Float16)0.f;
-        tile_store<false>(tiles, L::P_H0, pef[0], pef[1]);
-        tile_store<false>(tiles, L::P_H0 + 1, pef[2], zf);
-      }
-#define AVC_F_PARK(OFFB, OUT, PT)                                                            \
+      // every tile store below is issued by the hook of the NEXT layer (right after its first group barrier, see avc_mlp.h)
+#define AVC_F_ACT(OFFB, OUT)                                                                  \
   AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
           _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);  \
-          acc_to_frags(a, OUT[2 * t], OUT[2 * t + 1]);                                        \
-          tile_store<true>(tiles, (PT) + t, OUT[2 * t], OUT[2 * t + 1]);)
+          acc_to_frags(a, OUT[2 * t], OUT[2 * t + 1]);)
 #define AVC_F_LAST(OFFB)                                                                      \
   AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
           _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);  \
           load16(T + o.v[OFF_WL0_ACC], t, h, b);                                              \
           _Pragma("unroll") for (int r = 0; r < 16; ++r) part += b[r] * a[r];                 \
           acc_to_frags(a, hs[2 * t], hs[2 * t + 1]);                                          \
-          if constexpr (TRAIN) tile_store<false>(tiles, L::P_HS + t, hs[2 * t], hs[2 * t + 1]); \
           float w0[8], w1[8];                                                                 \
           load8(T + o.v[OFF_WL0_FRAG], 2 * t, h, w0); load8(T + o.v[OFF_WL0_FRAG], 2 * t + 1, h, w1); \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                     \
             g_s[2 * t][j] = (_Float16)(w0[j] * sig_from_h(a[j]));                             \
             g_s[2 * t + 1][j] = (_Float16)(w1[j] * sig_from_h(a[8 + j])); }                   \
-          pin2(g_s[2 * t], g_s[2 * t + 1]);                                                   \
-          if constexpr (TRAIN) tile_store<false>(tiles, L::P_GAS + t, g_s[2 * t], g_s[2 * t + 1]);)
+          pin2(g_s[2 * t], g_s[2 * t + 1]);)
       {
         h8 h1[N::HK];
-        layer_s<h8, 3, N::HT>(sg, Wf, o.v[OFF_W0], nxt<N, OFF_WM0>(sg, Wf, o), pef, AVC_F_PARK(OFF_B0, h1, L::P_H1));
+        layer_s<h8, 3, N::HT>(sg, Wf, o.v[OFF_W0], nxt<N, OFF_WM0>(sg, Wf, o), pef, AVC_F_ACT(OFF_B0, h1), AVC_HOOK(
+          if constexpr (TRAIN) {
+            h8 zf;
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) zf[j] = (_Float16)0.f;
+            tile_store<false>(tiles, L::P_H0, pef[0], pef[1]);
+            tile_store<false>(tiles, L::P_H0 + 1, pef[2], zf);
+          }));
         h8 hm0[N::HK];
         if constexpr (N::NMID == 2) {
-          layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wf, o), h1, AVC_F_PARK(OFF_BM0, hm0, L::P_HM));
+          layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wf, o), h1, AVC_F_ACT(OFF_BM0, hm0),
+                                    AVC_HOOK(tiles_store<true, N::HT>(tiles, L::P_H1, h1);));
           h8 hm1[N::HK];
-          layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wf, o), hm0,
-                                    AVC_F_PARK(OFF_BM1, hm1, L::P_HM + N::HT));
-          layer_s<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], nxt<N, OFF_WL>(sg, Wf, o), hm1, AVC_F_LAST(OFF_BS));
+          layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wf, o), hm0, AVC_F_ACT(OFF_BM1, hm1),
+                                    AVC_HOOK(tiles_store<true, N::HT>(tiles, L::P_HM, hm0);));
+          layer_s<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], nxt<N, OFF_WL>(sg, Wf, o), hm1, AVC_F_LAST(OFF_BS),
+                                    AVC_HOOK(tiles_store<true, N::HT>(tiles, L::P_HM + N::HT, hm1);));
         } else {
-          layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wf, o), h1, AVC_F_PARK(OFF_BM0, hm0, L::P_HM));
-          layer_s<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], nxt<N, OFF_WL>(sg, Wf, o), hm0, AVC_F_LAST(OFF_BS));
+          layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wf, o), h1, AVC_F_ACT(OFF_BM0, hm0),
+                                    AVC_HOOK(tiles_store<true, N::HT>(tiles, L::P_H1, h1);));
+          layer_s<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], nxt<N, OFF_WL>(sg, Wf, o), hm0, AVC_F_LAST(OFF_BS),
+                                    AVC_HOOK(tiles_store<true, N::HT>(tiles, L::P_HM, hm0);));
         }
       }
       sdf = xhalf_sum(part) + T[o.v[OFF_BL0]];
@@ -156,28 +178,34 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
         h8 f0, f1;
         acc_to_frags(a, f0, f1);
         tile_store<true>(tiles, L::P_FEAT + t, f0, f1);
-      ));
+      ), AVC_HOOK(
+        if constexpr (TRAIN && !ABL_NOMISC) {
+          tiles_store<false, N::ST>(tiles, L::P_HS, hs);
+          tiles_store<false, N::ST>(tiles, L::P_GAS, g_s);
+        }));
     }
     // ---------------------------------------------------------------- normal sweep: g_h(prev) = W^T g_a ; g_a(prev) = g_h sigma(h_prev)
     float n[3];
     {
-#define AVC_F_NSTEP(OUT, PH, PG)                                                                          \
-  AVC_PRE(return tile_load<false, h8>(tiles, (PH) + t);),                                                       \
+#define AVC_F_NSTEP(OUT, PH)                                                                              \
+  AVC_PRE(return tile_load<false, h8>(tiles, (PH) + t);),                                                   \
   AVC_EPID(FragPair<h8>, _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                    \
             OUT[2 * t][j] = (_Float16)(acc[j] * sig_from_h((float)d.a0[j]));                                \
             OUT[2 * t + 1][j] = (_Float16)(acc[8 + j] * sig_from_h((float)d.a1[j])); }                      \
-          pin2(OUT[2 * t], OUT[2 * t + 1]);                                                                 \
-          if constexpr (TRAIN) tile_store<false>(tiles, (PG) + t, OUT[2 * t], OUT[2 * t + 1]);)
+          pin2(OUT[2 * t], OUT[2 * t + 1]);)
+#define AVC_F_GSTORE(PG, G) AVC_HOOK(if constexpr (TRAIN && !ABL_NOGASTORE) tiles_store<false, N::HT>(tiles, PG, G);)
       h8 g[N::HK];
       h8 g2[N::HK];
       if constexpr (N::NMID == 2) {
-        layer_sq<h8, N::SK, N::HT>(sg, Wf, o.v[OFF_WST], nxt<N, OFF_WM1T>(sg, Wf, o), g_s,
-                                   AVC_F_NSTEP(g, L::P_HM + N::HT, L::P_GAM + N::HT));
-        layer_sq<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1T], nxt<N, OFF_WM0T>(sg, Wf, o), g, AVC_F_NSTEP(g2, L::P_HM, L::P_GAM));
-        layer_sq<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0T], nxt<N, OFF_W0T>(sg, Wf, o), g2, AVC_F_NSTEP(g, L::P_H1, L::P_GA1));
+        layer_sq<h8, N::SK, N::HT>(sg, Wf, o.v[OFF_WST], nxt<N, OFF_WM1T>(sg, Wf, o), g_s, AVC_F_NSTEP(g, L::P_HM + N::HT));
+        layer_sq<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1T], nxt<N, OFF_WM0T>(sg, Wf, o), g, AVC_F_NSTEP(g2, L::P_HM),
+                                   AVC_F_GSTORE(L::P_GAM + N::HT, g));
+        layer_sq<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0T], nxt<N, OFF_W0T>(sg, Wf, o), g2, AVC_F_NSTEP(g, L::P_H1),
+                                   AVC_F_GSTORE(L::P_GAM, g2));
       } else {
-        layer_sq<h8, N::SK, N::HT>(sg, Wf, o.v[OFF_WST], nxt<N, OFF_WM0T>(sg, Wf, o), g_s, AVC_F_NSTEP(g2, L::P_HM, L::P_GAM));
-        layer_sq<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0T], nxt<N, OFF_W0T>(sg, Wf, o), g2, AVC_F_NSTEP(g, L::P_H1, L::P_GA1));
+        layer_sq<h8, N::SK, N::HT>(sg, Wf, o.v[OFF_WST], nxt<N, OFF_WM0T>(sg, Wf, o), g_s, AVC_F_NSTEP(g2, L::P_HM));
+        layer_sq<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0T], nxt<N, OFF_W0T>(sg, Wf, o), g2, AVC_F_NSTEP(g, L::P_H1),
+                                   AVC_F_GSTORE(L::P_GAM, g2));
       }
       float part[3] = {0.f, 0.f, 0.f};
       const auto wpe = T + o.v[OFF_WL0_PE] + h * 24;
@@ -188,7 +216,7 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
           const int q = 16 * t + r;
           if (q < 24) part[q % 3] += pe2.d[q] * (acc[r] + wpe[q]);
         }
-      ));
+      ), AVC_F_GSTORE(L::P_GA1, g));
 #pragma unroll
       for (int c = 0; c < 3; ++c) n[c] = xhalf_sum(part[c]);
     }
@@ -202,12 +230,6 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
 #pragma unroll
         for (int c = 0; c < 3; ++c) { xn[0][c] = (_Float16)x[c]; xn[0][3 + c] = (_Float16)n[c]; }
       }
-      if constexpr (TRAIN) {
-        h8 zf;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) zf[j] = (_Float16)0.f;
-        tile_store<false>(tiles, L::P_XN, xn[0], zf);
-      }
       h8 feat[N::HK];
 #pragma unroll
       for (int t = 0; t < N::HT; ++t) {
@@ -216,32 +238,48 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
         feat[2 * t + 1] = d.a1;
       }
       // ReLU layers; TRAIN: the activations go out as weight-gradient operands and their sign bits (16 per tile and lane) as the
-      // masks of the backward pass
-#define AVC_F_RELU(OFFB, OUT, PT, ML)                                                         \
+      // masks of the backward pass -- both from the hook of the next layer
+#define AVC_F_RELU(OFFB, OUT, MB)                                                             \
   AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
           unsigned bits = 0u;                                                                 \
           _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                    \
             a[r] = fmaxf(acc[r] + b[r], 0.f); if (TRAIN) bits |= (a[r] > 0.f ? 1u : 0u) << r; } \
-          acc_to_frags(a, OUT[2 * t], OUT[2 * t + 1]);                                        \
-          if constexpr (TRAIN) {                                                              \
-            mk[((ML) * N::HT + t) * 64] = (unsigned short)bits;                               \
-            tile_store<false>(tiles, (PT) + t, OUT[2 * t], OUT[2 * t + 1]); })
+          if constexpr (TRAIN) MB[t] = bits;                                                  \
+          acc_to_frags(a, OUT[2 * t], OUT[2 * t + 1]);)
+#define AVC_F_RSTORE(PT, R, ML, MB)                                                           \
+  AVC_HOOK(if constexpr (TRAIN) {                                                             \
+             if (!ABL_NORSTORE) tiles_store<false, N::HT>(tiles, PT, R);                      \
+             if (!ABL_NOMASK) { _Pragma("unroll") for (int t = 0; t < N::HT; ++t) mk[((ML) * N::HT + t) * 64] = (unsigned short)MB[t]; } })
       h8 r1[N::HK];
       h8 r2[N::HK];
+      unsigned mb1[N::HT], mb2[N::HT];
       if constexpr (N::NCMID == 1) {
-        layer2_s<h8, N::HK, 1, N::HT>(sg, Wf, o.v[OFF_C0], nxt<N, OFF_CM0>(sg, Wf, o), feat, xn, AVC_F_RELU(OFF_CB0, r1, L::P_R1, 0));
-        layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_CM0], nxt<N, OFF_CH>(sg, Wf, o), r1, AVC_F_RELU(OFF_CBM0, r2, L::P_R2, 1));
+        layer2_s<h8, N::HK, 1, N::HT>(sg, Wf, o.v[OFF_C0], nxt<N, OFF_CM0>(sg, Wf, o), feat, xn, AVC_F_RELU(OFF_CB0, r1, mb1), AVC_HOOK(
+          if constexpr (TRAIN) {
+            h8 zf;
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) zf[j] = (_Float16)0.f;
+            tile_store<false>(tiles, L::P_XN, xn[0], zf);
+          }));
+        layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_CM0], nxt<N, OFF_CH>(sg, Wf, o), r1, AVC_F_RELU(OFF_CBM0, r2, mb2),
+                                  AVC_F_RSTORE(L::P_R1, r1, 0, mb1));
       } else {
-        layer2_s<h8, N::HK, 1, N::HT>(sg, Wf, o.v[OFF_C0], nxt<N, OFF_CH>(sg, Wf, o), feat, xn, AVC_F_RELU(OFF_CB0, r1, L::P_R1, 0));
+        layer2_s<h8, N::HK, 1, N::HT>(sg, Wf, o.v[OFF_C0], nxt<N, OFF_CH>(sg, Wf, o), feat, xn, AVC_F_RELU(OFF_CB0, r1, mb1), AVC_HOOK(
+          if constexpr (TRAIN) {
+            h8 zf;
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) zf[j] = (_Float16)0.f;
+            tile_store<false>(tiles, L::P_XN, xn[0], zf);
+          }));
 #pragma unroll
         for (int s = 0; s < N::HK; ++s) r2[s] = r1[s];
+#pragma unroll
+        for (int t = 0; t < N::HT; ++t) mb2[t] = mb1[t];
       }
       // the first tile of the next block iteration is prefetched under the head layer
       layer_s<h8, N::HK, 1>(sg, Wf, o.v[OFF_CH], nxt<N, OFF_W0>(sg, Wf0, o), r2, AVC_EPI(
         float b[16];
         load16(T + o.v[OFF_CBH], 0, h, b);
         _Pragma("unroll") for (int r = 0; r < 4; ++r) rgb[r] = sigmoidf_(acc[r] + b[r]);
-      ));
+      ), AVC_F_RSTORE((N::NCMID == 1 ? L::P_R2 : L::P_R1), r2, N::NCMID, mb2));
     }
     if (valid) {
       if (h == 0) {

@@ -18,6 +18,9 @@
 #define WG_TB_MAX 9
 #define WG_TILES_MAX 17
 #define WG_BUF_BYTES (WG_TILES_MAX * 2048)
+#ifndef WG_DEPTH
+#define WG_DEPTH 4   // blocks in the LDS ring (>= 3): one being contracted, one being transposed, WG_DEPTH - 2 copies in flight
+#endif
 
 template <typename V>
 __device__ __forceinline__ void make_sel(int lane, V& e0, V& e1) {
@@ -30,6 +33,24 @@ __device__ __forceinline__ void make_sel(int lane, V& e0, V& e1) {
     e1[j] = (typename MF<V>::S)(n == 16 + f ? 1.f : 0.f);
   }
 }
+// wait until at most `n` of this wave's vector-memory operations are outstanding (n is wave-uniform, <= 15 here)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // any other count: conservative
+  }
+}
 
 __device__ __forceinline__ void weight_grad_body(char* lds, const b8* __restrict__ panels, int ptiles, int pa, int ta_n, int pb,
                                                  int tb_n, int type_a, int type_b, long nblk, float* __restrict__ partial,
@@ -40,16 +61,15 @@ __device__ __forceinline__ void weight_grad_body(char* lds, const b8* __restrict
   const long b0 = nblk * split / nsplit, b1 = nblk * (split + 1) / nsplit;
   const int ntile = ta_n + tb_n;
   const int nchunk = ntile * 2;
-  char* raw = lds;                               // 2 x WG_BUF_BYTES: fragment-layout tiles as they arrive
-  char* tr = lds + 2 * WG_BUF_BYTES;             // WG_BUF_BYTES: transposed bf16 tiles of the current block
-  auto issue = [&](long blk, int buf) {
+  const int my_chunks = (nchunk - wv + 7) >> 3;   // DMA instructions this wave issues per block
+  auto issue = [&](long blk, int slot) {
     const char* base = reinterpret_cast<const char*>(panels + blk * (long)ptiles * 128);
     for (int c = wv; c < nchunk; c += 8) {
       const int tix = c >> 1;
       const int tile = tix < ta_n ? pa + tix : pb + (tix - ta_n);
       const char* g = base + ((long)tile * 128 + (c & 1) * 64 + lane) * 16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                       (__attribute__((address_space(3))) void*)(raw + buf * WG_BUF_BYTES + c * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(lds + slot * WG_BUF_BYTES + c * 1024), 16, 0, 0);
     }
   };
   h8 e0h, e1h;
@@ -63,15 +83,13 @@ __device__ __forceinline__ void weight_grad_body(char* lds, const b8* __restrict
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
   float bsum = 0.f;
   const bool own = wv < ta_n;
-  if (b0 < b1) issue(b0, 0);
-  int par = 0;
-  for (long blk = b0; blk < b1; ++blk) {
-    __syncthreads();   // block `blk` has landed (the barrier drains the DMA); every wave is done with the previous block's `tr`
-    if (blk + 1 < b1) issue(blk + 1, par ^ 1);
-    // transposition: the (ta+tb) tiles of the block are dealt to the 8 waves
+  // transposition IN PLACE of the block in ring slot `sl`: its (ta+tb) tiles are dealt to the 8 waves; a tile is read and
+  // rewritten by one wave only
+  auto transpose = [&](int sl) {
+    char* buf = lds + sl * WG_BUF_BYTES;
     for (int tix = wv; tix < ntile; tix += 8) {
-      const b8* src = reinterpret_cast<const b8*>(raw + par * WG_BUF_BYTES) + (tix * 2) * 64 + lane;
-      const b8 f0 = src[0], f1 = src[64];
+      b8* tp = reinterpret_cast<b8*>(buf) + (tix * 2) * 64 + lane;
+      const b8 f0 = tp[0], f1 = tp[64];
       facc t;
 #pragma unroll
       for (int r = 0; r < 16; ++r) t[r] = 0.f;
@@ -85,32 +103,70 @@ __device__ __forceinline__ void weight_grad_body(char* lds, const b8* __restrict
       b8 k0, k1;
 #pragma unroll
       for (int j = 0; j < 8; ++j) { k0[j] = (__bf16)t[j]; k1[j] = (__bf16)t[8 + j]; }
-      b8* dst = reinterpret_cast<b8*>(tr) + (tix * 2) * 64 + lane;
-      dst[0] = k0;
-      dst[64] = k1;
+      tp[0] = k0;
+      tp[64] = k1;
     }
-    // the transposed tiles are visible to every wave; a raw barrier, so that the DMA of the next block stays in flight across it
-    // (__syncthreads() would drain vmcnt first and serialise the copy with the contraction below)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  // Ring of WG_DEPTH block buffers.  Software pipeline with ONE barrier per block: in the interval of block b the waves contract
+  // block b (transposed during the previous interval) and transpose block b+1 (its copy has landed), while the copies of blocks
+  // b+2 .. b+WG_DEPTH-1 are in flight.  Raw barriers + counted vmcnt throughout: __syncthreads() would drain the copies.
+  for (int d = 0; d < WG_DEPTH - 1; ++d)
+    if (b0 + d < b1) issue(b0 + d, d);
+  if (b0 < b1) {
+    long younger = b1 - 1 - b0;
+    if (younger > WG_DEPTH - 2) younger = WG_DEPTH - 2;
+    wait_vmcnt((int)younger * my_chunks);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    transpose(0);
+  }
+  int slot = 0;
+  for (long blk = b0; blk < b1; ++blk) {
+    // this wave's chunks of block blk+1 have landed when at most the chunks of the younger blocks in flight are outstanding
+    // (LDS-DMA completes in issue order)
+    long younger = b1 - 2 - blk;
+    if (younger > WG_DEPTH - 3) younger = WG_DEPTH - 3;
+    if (younger < 0) younger = 0;
+    wait_vmcnt((int)younger * my_chunks);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my transposed tiles of block blk are written, my reads of block blk-1 are done
+    __builtin_amdgcn_s_barrier();                        // -> block blk is transposed, block blk+1 has landed, the slot of blk-1 is free
+    __builtin_amdgcn_sched_barrier(0);
+    if (blk + WG_DEPTH - 1 < b1) issue(blk + WG_DEPTH - 1, (slot + WG_DEPTH - 1) % WG_DEPTH);
     if (own) {
-      const b8* L = reinterpret_cast<const b8*>(tr) + lane;
+      const b8* L = reinterpret_cast<const b8*>(lds + slot * WG_BUF_BYTES) + lane;
       const b8 a0 = L[(wv * 2) * 64], a1 = L[(wv * 2 + 1) * 64];
       if (bias_partial) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) bsum += (float)a0[j] + (float)a1[j];
       }
+      // the B fragments are requested in batches of WG_BATCH ahead of their MFMAs (hipcc otherwise emits read -> wait -> MFMA
+      // per fragment: 20 exposed LDS round trips per block); two batches keep the kernel clear of spills
+#ifndef WG_BATCH
+#define WG_BATCH 5
+#endif
 #pragma unroll
-      for (int q = 0; q < WG_TB_MAX; ++q) {
-        if (q < tb_n) {
-          const b8 v0 = L[((ta_n + q) * 2) * 64], v1 = L[((ta_n + q) * 2 + 1) * 64];
-          acc[q] = MF<b8>::mma(a0, v0, acc[q]);
-          acc[q] = MF<b8>::mma(a1, v1, acc[q]);
+      for (int q0 = 0; q0 < WG_TB_MAX; q0 += WG_BATCH) {
+        b8 bv[WG_BATCH][2];
+#pragma unroll
+        for (int k = 0; k < WG_BATCH; ++k) {
+          if (q0 + k < WG_TB_MAX && q0 + k < tb_n) {
+            bv[k][0] = L[((ta_n + q0 + k) * 2) * 64];
+            bv[k][1] = L[((ta_n + q0 + k) * 2 + 1) * 64];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < WG_BATCH; ++k) asm volatile("" : "+v"(bv[k][0]), "+v"(bv[k][1]));
+#pragma unroll
+        for (int k = 0; k < WG_BATCH; ++k) {
+          if (q0 + k < WG_TB_MAX && q0 + k < tb_n) {
+            acc[q0 + k] = MF<b8>::mma(a0, bv[k][0], acc[q0 + k]);
+            acc[q0 + k] = MF<b8>::mma(a1, bv[k][1], acc[q0 + k]);
+          }
         }
       }
     }
-    par ^= 1;
+    if (blk + 1 < b1) transpose((slot + 1) % WG_DEPTH);
+    slot = (slot + 1) % WG_DEPTH;
   }
   if (own) {
     float* dst = partial + (long)split * out_elems;
@@ -158,7 +214,7 @@ extern "C" int avc_weight_grad_all(const void* panels, int ptiles, int npairs, c
     }
   }
   if (nsplit < 1) nsplit = 1;
-  const int lds_bytes = 3 * WG_BUF_BYTES;
+  const int lds_bytes = WG_DEPTH * WG_BUF_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)weight_grad_all_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);

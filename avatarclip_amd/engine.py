@@ -153,11 +153,19 @@ class Engine:
 
     def rays_per_chunk(self, R, S):
         """how many rays' operand panels fit the budget (see PANEL_BYTES_BUDGET)"""
+        need_all = ((R * S + 31) // 32 + 1) * self.ptiles * 2048
+        if self._panels is not None and self._panels.numel() >= need_all:
+            return R                   # the buffer at hand already holds the whole ray set (no driver query on the hot path:
+                                       # hipMemGetInfo synchronises with the device)
+        key = (R, S, self.PANEL_BYTES_BUDGET)
+        if getattr(self, "_chunk_key", None) == key and self._panels is not None:
+            return self._chunk_val
         have = self._panels.numel() if self._panels is not None else 0
         # 70 % of what is free once the current buffer is given back (it is released before a larger one is allocated)
         budget = max(min(self.PANEL_BYTES_BUDGET, (torch.cuda.mem_get_info(self.device)[0] + have) * 7 // 10), 1 << 28)
         max_blocks = max(1, budget // (self.ptiles * 2048) - 1)
-        return max(1, min(R, int(max_blocks * 32 // S) - 1))
+        self._chunk_key, self._chunk_val = key, max(1, min(R, int(max_blocks * 32 // S) - 1))
+        return self._chunk_val
 
     # ------------------------------------------------------------------ forward launches
     def sdf_rays(self, pk: Packed, rays_o, rays_d, z, sdf_out=None, slot=None, ld_out=0):

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, os.environ.get("AVC_LIB_NAME", "libavc.so"))
 SOURCES = ["avc_core.hip", "avc_mlp_fwd.hip", "avc_mlp_bwd.hip", "avc_wgrad.hip", "avc_rays.hip", "avc_vit.hip", "avc_mcubes.hip", "avc_raster.hip"]
-HEADERS = ["avc_common.h", "avc_stage.h", "avc_mlp.h", os.path.join("..", "..", "include", "avc.h")]
+HEADERS = ["avc_common.h", "avc_stage.h", "avc_mlp.h", "avc_offsets_gen.h", os.path.join("..", "..", "include", "avc.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"] + os.environ.get("AVC_EXTRA_FLAGS", "").split()
 
 
@@ -26,7 +26,17 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def _gen_offsets():
+    """csrc/avc_offsets_gen.h = the packed-blob offsets of packing.py as compile-time constants (scripts/gen_offsets.py)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_offsets", os.path.join(os.path.dirname(HERE), "scripts", "gen_offsets.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main()
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    _gen_offsets()
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, jobs = [], []

@@ -19,6 +19,13 @@ struct NetT {
 };
 typedef NetT<256, 2, 1> NetFull;
 typedef NetT<128, 1, 0> NetSmall;
+#include "avc_offsets_gen.h"
+// the launchers verify the table that came through the C ABI against the compiled-in one
+template <class N> static inline bool offsets_match(const int* offs) {
+  for (int k = 0; k < OFF_COUNT; ++k)
+    if (offs[k] != Off<N>::value.v[k]) return false;
+  return true;
+}
 
 struct PointSrc {
   const float* pts;      // [N,3] or nullptr -> ray mode
@@ -361,6 +368,7 @@ __device__ __forceinline__ float sdf_only(ST& sg, const h8* __restrict__ Wf, TP 
     const auto wpe = T + o.v[OFF_WL0_PE] + h * 24;
 #pragma unroll
     for (int q = 0; q < 24; ++q) part += wpe[q] * pe.v[q];
+    asm volatile("" : "+v"(part));   // done HERE (hipcc otherwise sinks the fmacs to the first use of `part` and keeps their operands alive)
   }
   h8 hlast[N::HK];
   {

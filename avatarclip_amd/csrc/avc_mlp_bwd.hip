@@ -43,11 +43,12 @@ struct PF3 { h8 h0, h1; b8 b0, b1; h8 g0, g1; };   // h, gbar_h, g_a tiles of on
 
 template <class N>
 __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long npts, const b8* __restrict__ Wb0,
-                                                               const float* __restrict__ T0, AvcOffsets o,
+                                                               const float* __restrict__ T0,
                                                                const float* __restrict__ d_sdf, const float* __restrict__ d_normal,
                                                                const float* __restrict__ d_rgb, const float* __restrict__ rgb_fwd,
                                                                char* __restrict__ panels, const unsigned short* __restrict__ masks) {
   typedef PanelLayout<N> L;
+  constexpr AvcOffsets o = Off<N>::value;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   typedef StageT<BWD_G> ST;
   const int lane = threadIdx.x & 63, h = lane >> 5, p = lane & 31;
@@ -235,8 +236,10 @@ extern "C" int avc_render_points_bwd(int net, const float* pts, const float* ray
                                      const float* rgb_fwd, void* panels, const void* masks, long max_waves, void* stream) {
   if (npts <= 0) return 0;
   if (!panels || !masks || !rgb_fwd) { avc_set_error("avc_render_points_bwd: panels / masks / rgb_fwd == NULL"); return 1; }
-  AvcOffsets o;
-  for (int k = 0; k < OFF_COUNT; ++k) o.v[k] = offs[k];
+  if (!(net == AVC_NET_FULL ? offsets_match<NetFull>(offs) : offsets_match<NetSmall>(offs))) {
+    avc_set_error("packed-blob offsets differ from the compiled-in table (regenerate csrc/avc_offsets_gen.h)");
+    return 1;
+  }
   PointSrc ps{pts, rays_o, rays_d, z, S, ldz, pts ? 0 : 1, sample_dist};
   const long nblk = (npts + 31) / 32;
   long ngroups = (nblk + BWD_WPB - 1) / BWD_WPB;
@@ -254,10 +257,10 @@ extern "C" int avc_render_points_bwd(int net, const float* pts, const float* ray
     attr_set = true;
   }
   if (net == AVC_NET_FULL)
-    hipLaunchKernelGGL((mlp_bwd_kernel<NetFull>), dim3(grid), dim3(64 * BWD_WPB), lds_bytes, s, ps, npts, (const b8*)wbf16, tab, o, d_sdf,
+    hipLaunchKernelGGL((mlp_bwd_kernel<NetFull>), dim3(grid), dim3(64 * BWD_WPB), lds_bytes, s, ps, npts, (const b8*)wbf16, tab, d_sdf,
                        d_normal, d_rgb, rgb_fwd, (char*)panels, (const unsigned short*)masks);
   else if (net == AVC_NET_SMALL)
-    hipLaunchKernelGGL((mlp_bwd_kernel<NetSmall>), dim3(grid), dim3(64 * BWD_WPB), lds_bytes, s, ps, npts, (const b8*)wbf16, tab, o, d_sdf,
+    hipLaunchKernelGGL((mlp_bwd_kernel<NetSmall>), dim3(grid), dim3(64 * BWD_WPB), lds_bytes, s, ps, npts, (const b8*)wbf16, tab, d_sdf,
                        d_normal, d_rgb, rgb_fwd, (char*)panels, (const unsigned short*)masks);
   else { avc_set_error("unknown net id"); return 1; }
   return avc_check_launch("avc_render_points_bwd");

@@ -34,9 +34,10 @@ constexpr bool ABL_NOMISC = false;
 
 template <class N>
 __global__ __launch_bounds__(64 * FWD_WPB) void mlp_sdf_kernel(PointSrc ps, long npts, const h8* __restrict__ Wf,
-                                                               const float* __restrict__ T, AvcOffsets o,
+                                                               const float* __restrict__ T,
                                                                float* __restrict__ sdf_out, const int* __restrict__ slot,
                                                                int ld_out) {
+  constexpr AvcOffsets o = Off<N>::value;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   typedef StageT<FWD_G> ST;
   const int lane = threadIdx.x & 63;
@@ -84,25 +85,34 @@ template <typename P> __device__ __forceinline__ P launder_ptr(P p) {
 
 template <class N, bool TRAIN>
 __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, long npts, const h8* __restrict__ Wf0,
-                                                                  const float* __restrict__ T0, AvcOffsets o,
+                                                                  const float* __restrict__ T0,
                                                                   float* __restrict__ sdf_out, float* __restrict__ normal_out,
                                                                   float* __restrict__ rgb_out, char* __restrict__ store,
                                                                   unsigned short* __restrict__ masks) {
+  constexpr AvcOffsets o = Off<N>::value;
   typedef typename std::conditional<TRAIN, PanelLayout<N>, ScratchLayout<N>>::type L;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   typedef StageT<FWD_G> ST;
-  const int lane = threadIdx.x & 63, h = lane >> 5, p = lane & 31;
+  const int lane0 = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const long nblk = (npts + 31) >> 5;
   const long wslot = (long)blockIdx.x * FWD_WPB + wv;
   char* slot0 = store + wslot * (long)L::P_TILES * 2048;   // TRAIN = false: this wave's private slot
   ST sg = stage_init<FWD_G>(lds);
   stage_issue(sg, nxt<N, OFF_W0>(sg, Wf0, o), 0);
-  const lds_tab_t T = tab_to_lds(lds + ST::LDS_BYTES, T0, o.v[OFF_TAB_END]);
+  const lds_tab_t Tl = tab_to_lds(lds + ST::LDS_BYTES, T0, o.v[OFF_TAB_END]);
   __syncthreads();
   for (long blk0 = (long)blockIdx.x * FWD_WPB; blk0 < nblk; blk0 += (long)gridDim.x * FWD_WPB) {
-    // opaque per iteration: otherwise LICM hoists the loop-invariant addresses out of the loop and spills them
+    // opaque per iteration: otherwise LICM hoists the loop-invariant addresses (weight tiles, ~25 per-lane table addresses) out of
+    // the persistent loop and spills them at its top
     const h8* Wf = launder_ptr(Wf0);
+    lds_tab_t T = Tl;
+    asm volatile("" : "+s"(T));
+    // ... and every lane-derived constant (fragment / table addresses, PE frequencies): recomputed per block from an opaque lane id
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int h = lane >> 5, p = lane & 31;
+    sg.lane = lane;
     const long blk = blk0 + wv;
     // TRAIN: block nblk of the panel / mask buffers is a sink for the wavefronts past the end (they walk the tile sequence for the barriers)
     const PanelPtr tiles = panel_ptr(TRAIN ? store + (blk < nblk ? blk : nblk) * (long)L::P_TILES * 2048 : slot0, lane);
@@ -124,6 +134,8 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
         const auto wpe = T + o.v[OFF_WL0_PE] + h * 24;
 #pragma unroll
         for (int q = 0; q < 24; ++q) part += wpe[q] * pe.v[q];
+        asm volatile("" : "+v"(part));   // done HERE: hipcc otherwise sinks the 24 fmacs to the first use of `part`, three layers
+                                         // down, and keeps (spills, then reloads one by one) their 48 operands until then
       }
       h8 pef[3];
       pe_to_frags_f16(pe, x, h, pef);
@@ -209,8 +221,12 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
       }
       float part[3] = {0.f, 0.f, 0.f};
       const auto wpe = T + o.v[OFF_WL0_PE] + h * 24;
+      // the PE derivatives are RE-computed here from an opaque copy of x: hipcc otherwise merges this call with the one at the top
+      // of the block and keeps its 48 values alive across the whole trunk (59 spill stores + 35 reloads per block)
+      float x2[3] = {x[0], x[1], x[2]};
+      asm volatile("" : "+v"(x2[0]), "+v"(x2[1]), "+v"(x2[2]));
       PE pe2;
-      pe_compute(x, h, pe2);
+      pe_compute(x2, h, pe2);
       layer_s<h8, N::HK, 2>(sg, Wf, o.v[OFF_W0T], nxt<N, OFF_C0>(sg, Wf, o), g, AVC_EPI(
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {
           const int q = 16 * t + r;
@@ -239,31 +255,28 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
       }
       // ReLU layers; TRAIN: the activations go out as weight-gradient operands and their sign bits (16 per tile and lane) as the
       // masks of the backward pass -- both from the hook of the next layer
-#define AVC_F_RELU(OFFB, OUT, MB)                                                             \
+#define AVC_F_RELU(OFFB, OUT, ML)                                                             \
   AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
           unsigned bits = 0u;                                                                 \
           _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                    \
             a[r] = fmaxf(acc[r] + b[r], 0.f); if (TRAIN) bits |= (a[r] > 0.f ? 1u : 0u) << r; } \
-          if constexpr (TRAIN) MB[t] = bits;                                                  \
+          if constexpr (TRAIN && !ABL_NOMASK) mk[((ML) * N::HT + t) * 64] = (unsigned short)bits; \
           acc_to_frags(a, OUT[2 * t], OUT[2 * t + 1]);)
-#define AVC_F_RSTORE(PT, R, ML, MB)                                                           \
-  AVC_HOOK(if constexpr (TRAIN) {                                                             \
-             if (!ABL_NORSTORE) tiles_store<false, N::HT>(tiles, PT, R);                      \
-             if (!ABL_NOMASK) { _Pragma("unroll") for (int t = 0; t < N::HT; ++t) mk[((ML) * N::HT + t) * 64] = (unsigned short)MB[t]; } })
+#define AVC_F_RSTORE(PT, R)                                                                   \
+  AVC_HOOK(if constexpr (TRAIN && !ABL_NORSTORE) tiles_store<false, N::HT>(tiles, PT, R);)
       h8 r1[N::HK];
       h8 r2[N::HK];
-      unsigned mb1[N::HT], mb2[N::HT];
       if constexpr (N::NCMID == 1) {
-        layer2_s<h8, N::HK, 1, N::HT>(sg, Wf, o.v[OFF_C0], nxt<N, OFF_CM0>(sg, Wf, o), feat, xn, AVC_F_RELU(OFF_CB0, r1, mb1), AVC_HOOK(
+        layer2_s<h8, N::HK, 1, N::HT>(sg, Wf, o.v[OFF_C0], nxt<N, OFF_CM0>(sg, Wf, o), feat, xn, AVC_F_RELU(OFF_CB0, r1, 0), AVC_HOOK(
           if constexpr (TRAIN) {
             h8 zf;
             _Pragma("unroll") for (int j = 0; j < 8; ++j) zf[j] = (_Float16)0.f;
             tile_store<false>(tiles, L::P_XN, xn[0], zf);
           }));
-        layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_CM0], nxt<N, OFF_CH>(sg, Wf, o), r1, AVC_F_RELU(OFF_CBM0, r2, mb2),
-                                  AVC_F_RSTORE(L::P_R1, r1, 0, mb1));
+        layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_CM0], nxt<N, OFF_CH>(sg, Wf, o), r1, AVC_F_RELU(OFF_CBM0, r2, 1),
+                                  AVC_F_RSTORE(L::P_R1, r1));
       } else {
-        layer2_s<h8, N::HK, 1, N::HT>(sg, Wf, o.v[OFF_C0], nxt<N, OFF_CH>(sg, Wf, o), feat, xn, AVC_F_RELU(OFF_CB0, r1, mb1), AVC_HOOK(
+        layer2_s<h8, N::HK, 1, N::HT>(sg, Wf, o.v[OFF_C0], nxt<N, OFF_CH>(sg, Wf, o), feat, xn, AVC_F_RELU(OFF_CB0, r1, 0), AVC_HOOK(
           if constexpr (TRAIN) {
             h8 zf;
             _Pragma("unroll") for (int j = 0; j < 8; ++j) zf[j] = (_Float16)0.f;
@@ -271,15 +284,13 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
           }));
 #pragma unroll
         for (int s = 0; s < N::HK; ++s) r2[s] = r1[s];
-#pragma unroll
-        for (int t = 0; t < N::HT; ++t) mb2[t] = mb1[t];
       }
       // the first tile of the next block iteration is prefetched under the head layer
       layer_s<h8, N::HK, 1>(sg, Wf, o.v[OFF_CH], nxt<N, OFF_W0>(sg, Wf0, o), r2, AVC_EPI(
         float b[16];
         load16(T + o.v[OFF_CBH], 0, h, b);
         _Pragma("unroll") for (int r = 0; r < 4; ++r) rgb[r] = sigmoidf_(acc[r] + b[r]);
-      ), AVC_F_RSTORE((N::NCMID == 1 ? L::P_R2 : L::P_R1), r2, N::NCMID, mb2));
+      ), AVC_F_RSTORE((N::NCMID == 1 ? L::P_R2 : L::P_R1), r2));
     }
     if (valid) {
       if (h == 0) {
@@ -320,8 +331,10 @@ static int launch_sdf(int net, PointSrc ps, long npts, const void* wf, const flo
                       float* sdf_out, const int* slot, int ld_out, void* stream) {
   if (npts <= 0) return 0;
   if (check_tab(offs)) return 1;
-  AvcOffsets o;
-  for (int k = 0; k < OFF_COUNT; ++k) o.v[k] = offs[k];
+  if (!(net == AVC_NET_FULL ? offsets_match<NetFull>(offs) : offsets_match<NetSmall>(offs))) {
+    avc_set_error("packed-blob offsets differ from the compiled-in table (regenerate csrc/avc_offsets_gen.h)");
+    return 1;
+  }
   hipStream_t s = (hipStream_t)stream;
   const int wpb = FWD_WPB;   // wavefronts per workgroup
   const int grid = grid_for(npts, wpb, 0x7fffffff);
@@ -333,10 +346,10 @@ static int launch_sdf(int net, PointSrc ps, long npts, const void* wf, const flo
     attr_set = true;
   }
   if (net == AVC_NET_FULL)
-    hipLaunchKernelGGL((mlp_sdf_kernel<NetFull>), dim3(grid), dim3(64 * wpb), lds_bytes, s, ps, npts, (const h8*)wf, tab, o,
+    hipLaunchKernelGGL((mlp_sdf_kernel<NetFull>), dim3(grid), dim3(64 * wpb), lds_bytes, s, ps, npts, (const h8*)wf, tab,
                        sdf_out, slot, ld_out);
   else if (net == AVC_NET_SMALL)
-    hipLaunchKernelGGL((mlp_sdf_kernel<NetSmall>), dim3(grid), dim3(64 * wpb), lds_bytes, s, ps, npts, (const h8*)wf, tab, o,
+    hipLaunchKernelGGL((mlp_sdf_kernel<NetSmall>), dim3(grid), dim3(64 * wpb), lds_bytes, s, ps, npts, (const h8*)wf, tab,
                        sdf_out, slot, ld_out);
   else {
     avc_set_error("unknown net id");
@@ -357,8 +370,10 @@ static int launch_render(int net, PointSrc ps, long npts, const void* wf16, cons
                          float* normal_out, float* rgb_out, long max_waves, void* store, void* masks, void* stream,
                          const char* what) {
   if (check_tab(offs)) return 1;
-  AvcOffsets o;
-  for (int k = 0; k < OFF_COUNT; ++k) o.v[k] = offs[k];
+  if (!(net == AVC_NET_FULL ? offsets_match<NetFull>(offs) : offsets_match<NetSmall>(offs))) {
+    avc_set_error("packed-blob offsets differ from the compiled-in table (regenerate csrc/avc_offsets_gen.h)");
+    return 1;
+  }
   long maxg = max_waves / FWD_WPB;
   if (maxg < 1) maxg = 1;
   const int grid = grid_for(npts, FWD_WPB, (int)(maxg < 0x7fffffff ? maxg : 0x7fffffff));
@@ -371,10 +386,10 @@ static int launch_render(int net, PointSrc ps, long npts, const void* wf16, cons
     attr_set = true;
   }
   if (net == AVC_NET_FULL)
-    hipLaunchKernelGGL((mlp_render_kernel<NetFull, TRAIN>), dim3(grid), dim3(64 * FWD_WPB), lds_bytes, s, ps, npts, (const h8*)wf16, tab, o,
+    hipLaunchKernelGGL((mlp_render_kernel<NetFull, TRAIN>), dim3(grid), dim3(64 * FWD_WPB), lds_bytes, s, ps, npts, (const h8*)wf16, tab,
                        sdf_out, normal_out, rgb_out, (char*)store, (unsigned short*)masks);
   else if (net == AVC_NET_SMALL)
-    hipLaunchKernelGGL((mlp_render_kernel<NetSmall, TRAIN>), dim3(grid), dim3(64 * FWD_WPB), lds_bytes, s, ps, npts, (const h8*)wf16, tab, o,
+    hipLaunchKernelGGL((mlp_render_kernel<NetSmall, TRAIN>), dim3(grid), dim3(64 * FWD_WPB), lds_bytes, s, ps, npts, (const h8*)wf16, tab,
                        sdf_out, normal_out, rgb_out, (char*)store, (unsigned short*)masks);
   else {
     avc_set_error("unknown net id");

@@ -28,6 +28,23 @@ F_SDF, F_GRAD, F_COL = 524800, 393728, 268288
 F_PT = F_SDF + F_GRAD + F_COL
 F_SDF_ONLY = 2 * (39 * 256 + 2 * 256 * 256 + 256 * 217 + 256)   # SDF value only (row 0 of the last layer)
 PEAK_MFMA = 2.5e15   # dense bf16/f16 MFMA, MI355X_MICROARCH.md
+PEAK_HBM = 8.0e12    # HBM3E, MI355X_MICROARCH.md (6.3e12 achievable for a pure copy)
+TILE = 64            # bytes per point of one 32-feature operand tile (2 KiB per 32-point block)
+# The MLP kernels of one training step, each with the roofline that bounds it:
+#   algorithmic FLOPs per point: SURVEY.md 8d; algorithmic bytes per point: the operand tiles a kernel must read once and write once
+#   (full nets: 180 tiles = 11.25 KiB per point in total: 89 written by the forward kernel, 91 by the backward kernel)
+KERNEL_ROOFLINES = {
+    "avc_render_points_fwd_train": dict(kernel="mlp_render_kernel<train>", bound="mfma", flop_per_point=F_PT, bytes_per_point=89 * TILE + 76,
+                                        note="differentiable forward (F_pt = 1 186 816 FLOP/point) + the forward-type operand tiles; "
+                                             "matrix / vector work of the epilogues bounds it, the tile stores ride along"),
+    "avc_render_points_bwd": dict(kernel="mlp_bwd_kernel", bound="hbm", flop_per_point=F_PT, bytes_per_point=(91 + 62) * TILE + 80,
+                                  note="colour backward + second-order + reverse sweep (F_pt FLOP/point, no forward recompute); HBM-bound: "
+                                       "writes 91 gradient-type tiles, reads h and g_a (62 tiles) -- its own gbar_h / ybar re-reads "
+                                       "(70 tiles) are on top of the algorithmic bytes"),
+    "avc_weight_grad(all pairs)": dict(kernel="weight_grad_all_kernel", bound="hbm", flop_per_point=F_PT, bytes_per_point=180 * TILE,
+                                       note="dW = sum_points A^T B from the operand panels (F_pt FLOP/point, AI = 103 FLOP/B < ridge 312): "
+                                            "HBM-bound by construction; 203 tile reads per block for 180 distinct tiles"),
+}
 
 
 def make_conf(res, spp, small=False):
@@ -148,7 +165,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--small", action="store_true", help="128-wide nets (confs/examples_small)")
@@ -217,26 +234,40 @@ def main():
 
     if rank == 0:
         rays_per_step = args.res * args.res * world
-        # dominant kernel: mlp_bwd_kernel (avc_render_points_bwd); events recorded on the launch stream
+        # per-kernel launch times from events recorded on the launch stream (Engine._Timed)
         per_kernel = {}
         for name, npts, e0, e1 in Engine.prof_events:
             per_kernel.setdefault(name, []).append((npts, e0.elapsed_time(e1) * 1e-3))
-        roof = None
-        if "avc_render_points_bwd" in per_kernel and not args.small:
-            recs = per_kernel["avc_render_points_bwd"]
-            avg_t = float(np.mean([t for _, t in recs]))
-            avg_pts = float(np.mean([n for n, _ in recs]))
-            flops = 2.0 * F_PT * avg_pts          # forward recompute + every dX product (incl. double backward)
-            # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_summary.md: FETCH_SIZE x2 + WRITE_SIZE,
-            # separate rocprofv3 --pmc runs of this same command); scaled to this run's points per launch
-            traffic = 25.7e9 * avg_pts / 1048576.0
-            roof = {"kernel": "mlp_bwd_kernel (avc_render_points_bwd)", "bound": "mfma", "achieved": flops / avg_t / 1e12,
-                    "peak": PEAK_MFMA / 1e12, "unit": "TFLOP/s", "frac": flops / avg_t / PEAK_MFMA, "traffic": traffic,
-                    "traffic_note": "HBM bytes per launch from the rocprofv3 PMC passes of this command (profiles/r01_pmc_summary.md: "
-                                    "2 x FETCH_SIZE + WRITE_SIZE = 24.5 KiB/point); algorithmic bytes are the 11.25 KiB/point of "
-                                    "weight-gradient panels: the kernel runs at ~5.0 TB/s, i.e. it is HBM-bound, not MFMA-bound",
-                    "avg_launch_ms": avg_t * 1e3, "points_per_launch": avg_pts, "launches": len(recs),
-                    "algorithmic_flop_per_point": 2.0 * F_PT}
+        # HBM traffic per point measured with the PMC counters (separate rocprofv3 --pmc passes of this command, summarised by
+        # scripts/pmc_summary.py --json into profiles/): 2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction
+        pmc = {}
+        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as fh:
+                pmc = json.load(fh)
+        roofs = {}
+        if not args.small:
+            for name, spec in KERNEL_ROOFLINES.items():
+                if name not in per_kernel:
+                    continue
+                recs = per_kernel[name]
+                avg_t = float(np.mean([t for _, t in recs]))
+                avg_pts = float(np.mean([n for n, _ in recs]))
+                flops, nbytes = spec["flop_per_point"] * avg_pts, spec["bytes_per_point"] * avg_pts
+                mfma_frac, hbm_frac = flops / avg_t / PEAK_MFMA, nbytes / avg_t / PEAK_HBM
+                tr = pmc.get("kernels", {}).get(spec["kernel"])
+                r = {"kernel": "%s (%s)" % (spec["kernel"], name), "bound": spec["bound"],
+                     "achieved": (nbytes / avg_t / 1e9) if spec["bound"] == "hbm" else (flops / avg_t / 1e12),
+                     "peak": (PEAK_HBM / 1e9) if spec["bound"] == "hbm" else (PEAK_MFMA / 1e12),
+                     "unit": "GB/s" if spec["bound"] == "hbm" else "TFLOP/s", "frac": hbm_frac if spec["bound"] == "hbm" else mfma_frac,
+                     "traffic": (tr["bytes_per_point"] * avg_pts) if tr else None,
+                     "traffic_source": ("profiles/r02_pmc_traffic.json (commit %s, %s)" % (pmc.get("commit"), pmc.get("box"))) if tr else None,
+                     "avg_launch_ms": avg_t * 1e3, "points_per_launch": avg_pts, "launches": len(recs),
+                     "algorithmic_flop_per_point": spec["flop_per_point"], "algorithmic_bytes_per_point": spec["bytes_per_point"],
+                     "mfma_frac": mfma_frac, "hbm_frac_algorithmic": hbm_frac, "note": spec["note"]}
+                roofs[name] = r
+        dominant = max(roofs, key=lambda k: roofs[k]["avg_launch_ms"] * roofs[k]["launches"]) if roofs else None
+        roof = roofs.get(dominant)
         kern_ms = {k: 1e3 * float(np.sum([t for _, t in v])) / args.steps for k, v in per_kernel.items()}
         out = {
             "metric": "rays_per_sec_512x512_64spp_clip_guided_train_iter",
@@ -259,6 +290,7 @@ def main():
                        "parallelism": "view-sharded dp%d, one flat RCCL all-reduce/step" % world},
             "kernel_ms_per_step": kern_ms,
             "roofline": roof,
+            "roofline_all": roofs,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.spp)

@@ -51,18 +51,25 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
   constexpr AvcOffsets o = Off<N>::value;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   typedef StageT<BWD_G> ST;
-  const int lane = threadIdx.x & 63, h = lane >> 5, p = lane & 31;
+  const int lane0 = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const long nblk = (npts + 31) >> 5;
   ST sg = stage_init<BWD_G>(lds);
   stage_issue(sg, nxt<N, OFF_CHT>(sg, Wb0, o), 0);
   // the fp32 table lives in LDS: a global load in an epilogue would queue behind the LDS-DMA of the next weight group
-  const lds_tab_t T = tab_to_lds(lds + ST::LDS_BYTES, T0, o.v[OFF_TAB_END]);
+  const lds_tab_t Tl = tab_to_lds(lds + ST::LDS_BYTES, T0, o.v[OFF_TAB_END]);
   __syncthreads();
 
   // every wavefront of a workgroup runs the same number of iterations (workgroup-uniform loop bound)
   for (long blk0 = (long)blockIdx.x * BWD_WPB; blk0 < nblk; blk0 += (long)gridDim.x * BWD_WPB) {
     const b8* Wb = launder(Wb0);
+    // per-iteration copies of the loop invariants: otherwise everything derived from them is hoisted out of the loop and spilled
+    lds_tab_t T = Tl;
+    asm volatile("" : "+s"(T));
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int h = lane >> 5, p = lane & 31;
+    sg.lane = lane;
     const long blk = blk0 + wv;
     // wavefronts past the end walk the tile sequence for the barriers and write to the sink block (index nblk)
     const PanelPtr tiles = panel_ptr(panels + (blk < nblk ? blk : nblk) * (long)L::P_TILES * 2048, lane);

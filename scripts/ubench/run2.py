@@ -48,3 +48,12 @@ if "atomic" in sys.argv or len(sys.argv) == 1:
             print("%-58s grid %4d: %8.3f ms  %8.1f GB/s of merged tiles (%.2f Gadd/s)  sum check %s  xcc histogram %s"
                   % (name, grid, ms, gb / (ms * 1e-3), gb / 4 / (ms * 1e-3), "OK" if abs(total - expect) < 1e-3 * expect else "BAD %g vs %g" % (total, expect),
                      xcc.tolist() if mode < 2 else "-"), flush=True)
+
+if "copy" in sys.argv:
+    # counter calibration (run under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE): 4 GiB read + 4 GiB written per launch
+    lib.ub2_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    ntiles = 1 << 21
+    src = torch.zeros(ntiles * 512, dtype=torch.int32, device="cuda"); dst = torch.empty_like(src)
+    for nt in (0, 1):
+        ms = timed(lambda: lib.ub2_copy(src.data_ptr(), dst.data_ptr(), ntiles, nt, 2048, st))
+        print("copy of %d tiles x 2 KiB (nt=%d): %.3f ms, %.0f GB/s read + the same written" % (ntiles, nt, ms, ntiles * 2048 / ms / 1e6), flush=True)

@@ -88,3 +88,25 @@ extern "C" int ub2_atomic(int mode, int grid, int passes, int tile_floats, float
   else hipLaunchKernelGGL(ub2_rmw_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, buf, buf_stride, passes, tile_floats);
   return (int)hipGetLastError();
 }
+
+// ---- (3) counter calibration: a copy of KNOWN size with the panel access pattern (one wavefront moves 2 KiB tiles, 16 B per
+// lane and instruction), so FETCH_SIZE / WRITE_SIZE of rocprofv3 can be checked against bytes that are certain.
+typedef int v4i __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void ub2_copy_kernel(const v4i* __restrict__ src, v4i* __restrict__ dst, long ntiles, int nt) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 8 + (threadIdx.x >> 6), nw = (long)gridDim.x * 8;
+  for (long t = wave; t < ntiles; t += nw) {
+    const v4i* s = src + t * 128 + lane;
+    v4i* d = dst + t * 128 + lane;
+    v4i a, b;
+    if (nt) { a = __builtin_nontemporal_load(s); b = __builtin_nontemporal_load(s + 64); }
+    else { a = s[0]; b = s[64]; }
+    a.x += 1; b.y += 1;
+    if (nt) { __builtin_nontemporal_store(a, d); __builtin_nontemporal_store(b, d + 64); }
+    else { d[0] = a; d[64] = b; }
+  }
+}
+extern "C" int ub2_copy(const void* src, void* dst, long ntiles, int nt, int grid, void* stream) {
+  hipLaunchKernelGGL(ub2_copy_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, (const v4i*)src, (v4i*)dst, ntiles, nt);
+  return (int)hipGetLastError();
+}

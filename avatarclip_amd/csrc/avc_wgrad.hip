@@ -5,35 +5,32 @@
 
 // ---------------------------------------------------------------------------------------------
 // partial[split][ta][tb] = sum over the split's 32-point blocks, sum_kappa A[blk][ta][kappa] x B[blk][tb][kappa]
-// One 8-wave workgroup per (K-split, pair).  Per block the (ta+tb) panel tiles are copied ONCE into LDS by global->LDS DMA
-// (double buffered, the copy of block b+1 runs under the work on block b).  The tiles arrive in the producers' FRAGMENT layout
-// (lane = point, 8 features per k-step); the contraction over points needs them feature-major (lane = feature, 16 points per
-// lane).  The transposition runs on the matrix core: two MFMAs against a 0/1 selection fragment turn a 32 x 32 tile from
-// lane = point to lane = feature (exact); the waves share the (ta+tb) tiles of a block, write the bf16 results to a second
-// LDS area, and after one more barrier wave w contracts A tile w with all tb B tiles (<= 9 accumulators).
-// (Round 1 transposed in the producers, twice per re-read tile; here it costs ~2 MFMAs per tile and block in a kernel whose
-// matrix pipe idles behind HBM.)  Partials are written with plain stores and summed on the host side of the ABI (no atomics).
+// One 8-wave workgroup per (K-split, pair).  Per block the (ta+tb) panel tiles are copied ONCE into an LDS ring by
+// global->LDS DMA (WG_DEPTH - 1 blocks in flight under the work on the current one).  The tiles arrive in the producers'
+// FRAGMENT layout (lane = point, 8 features per k-step); the contraction over points needs them feature-major (lane =
+// feature, 8 points per lane).  gfx950's LDS transpose read does that on the way into the registers: ds_read_b64_tr_b16
+// hands lane i of a 16-lane group element (i & 3) of the 8 bytes addressed by lane 4 j + (i >> 2) of the group, for j = 0..3,
+// i.e. the column i of a [4 points][16 features] block.  The DMA therefore deals the 16-byte chunks of a tile (chunk (s,h,p)
+// = features 16 s + 8 (j >> 2) + 4 h + (j & 3) of point p) to the LDS position (p >> 2) * 16 + (2 s + h) * 4 + (p & 3): the 32
+// lanes of a half-wave then read 256 contiguous bytes (no bank conflict) and every DMA instruction still reads whole
+// 256-byte runs of the panel.  (Round 1 transposed in the producers; the first round-2 kernel transposed on the matrix core
+// in a separate pass through LDS: 68 KiB of extra LDS traffic and one more pipeline stage per block.)
+// The 8 waves split the ta x tb output tiles 4 x 2 (2 A tiles x 4 B tiles per wave: 6 tile reads for 8 products) when both
+// sides are wide, 8 x 1 or 1 x 8 otherwise.  One operand of every pair is f16 (forward-type), the other bf16: the f16 side is
+// converted after the read.  Partials are written with plain stores and summed on the host side of the ABI (no atomics).
 // HBM-bound by construction: 2 KiB per tile per block is read exactly once per pair it takes part in.
 // ---------------------------------------------------------------------------------------------
 #define WG_TB_MAX 9
 #define WG_TILES_MAX 17
 #define WG_BUF_BYTES (WG_TILES_MAX * 2048)
 #ifndef WG_DEPTH
-#define WG_DEPTH 4   // blocks in the LDS ring (>= 3): one being contracted, one being transposed, WG_DEPTH - 2 copies in flight
+#define WG_DEPTH 4   // blocks in the LDS ring: one being contracted, WG_DEPTH - 1 copies in flight
 #endif
 
-template <typename V>
-__device__ __forceinline__ void make_sel(int lane, V& e0, V& e1) {
-  // selection fragments: lane (n,h) of k-step-half e: 1 where feature slot (h,j) == n
-  const int n = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int f = 8 * (j >> 2) + 4 * h + (j & 3);
-    e0[j] = (typename MF<V>::S)(n == f ? 1.f : 0.f);
-    e1[j] = (typename MF<V>::S)(n == 16 + f ? 1.f : 0.f);
-  }
-}
-// wait until at most `n` of this wave's vector-memory operations are outstanding (n is wave-uniform, <= 15 here)
+typedef short vs4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef __attribute__((address_space(3))) char lds_char;
+
+// wait until at most `n` of this wave's vector-memory operations are outstanding (n is wave-uniform)
 __device__ __forceinline__ void wait_vmcnt(int n) {
   switch (n) {
     case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -52,138 +49,139 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
   }
 }
 
+// operand fragment of k-step t (points 16 t .. 16 t + 15) of the tile at LDS address `tile` (+ this lane's offset): lane
+// (feature m = lane & 31, hh = lane >> 5) receives points 16 t + 8 hh + 0..7
+__device__ __forceinline__ b8 tr_frag(lds_char* p, int t) {
+  struct { vs4 lo, hi; } r;
+  r.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<__attribute__((address_space(3))) vs4*>(p + t * 1024));
+  r.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<__attribute__((address_space(3))) vs4*>(p + t * 1024 + 256));
+  return __builtin_bit_cast(b8, r);
+}
+__device__ __forceinline__ b8 f16_to_bf16(b8 v) {
+  const h8 x = __builtin_bit_cast(h8, v);
+  b8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (__bf16)(float)x[j];
+  return o;
+}
+
+// NI x NK output tiles per wave: A tiles wa + WA i, B tiles wb + WB k
+template <int NI, int NK>
 __device__ __forceinline__ void weight_grad_body(char* lds, const b8* __restrict__ panels, int ptiles, int pa, int ta_n, int pb,
                                                  int tb_n, int type_a, int type_b, long nblk, float* __restrict__ partial,
-                                                 float* __restrict__ bias_partial, int out_elems, int bias_elems) {
+                                                 float* __restrict__ bias_partial, int out_elems, int bias_elems, int WA) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int WB = 8 / WA;
+  const int wa = wv % WA, wb = wv / WA;
   const int split = blockIdx.x, nsplit = gridDim.x;   // (the pair index is blockIdx.y)
   const long b0 = nblk * split / nsplit, b1 = nblk * (split + 1) / nsplit;
   const int ntile = ta_n + tb_n;
   const int nchunk = ntile * 2;
   const int my_chunks = (nchunk - wv + 7) >> 3;   // DMA instructions this wave issues per block
+  // source chunk of this lane in DMA instruction c of a tile: LDS position 64 c + lane = (p >> 2) * 16 + (2 s + h) * 4 + (p & 3)
+  const int src_lo = ((lane >> 2) & 3) * 32 + 4 * (lane >> 4) + (lane & 3);   // (2 s + h) * 32 + p with p = 4 (lane >> 4) + (lane & 3)
   auto issue = [&](long blk, int slot) {
     const char* base = reinterpret_cast<const char*>(panels + blk * (long)ptiles * 128);
     for (int c = wv; c < nchunk; c += 8) {
       const int tix = c >> 1;
       const int tile = tix < ta_n ? pa + tix : pb + (tix - ta_n);
-      const char* g = base + ((long)tile * 128 + (c & 1) * 64 + lane) * 16;
+      const char* g = base + ((long)tile * 128 + src_lo + (c & 1) * 16) * 16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                        (__attribute__((address_space(3))) void*)(lds + slot * WG_BUF_BYTES + c * 1024), 16, 0, 0);
     }
   };
-  h8 e0h, e1h;
-  b8 e0b, e1b;
-  make_sel<h8>(lane, e0h, e1h);
-  make_sel<b8>(lane, e0b, e1b);
-  facc acc[WG_TB_MAX];
+  // this lane's byte offset inside a tile for the transpose reads: group g = lane >> 4 = 2 hh + s, i = lane & 15 supplies
+  // the 8 bytes (half c >> 1 of chunk (s, h' = c & 1, p = p0 + r)), r = i >> 2, c = i & 3;  p0 = 16 t + 8 hh + 4 u
+  const int lane_off = (((lane >> 5) * 2) * 16 + (((lane >> 4) & 1) * 2 + (lane & 1)) * 4 + ((lane & 15) >> 2)) * 16 + 8 * ((lane & 3) >> 1);
+  facc acc[NI * NK];
 #pragma unroll
-  for (int q = 0; q < WG_TB_MAX; ++q)
+  for (int q = 0; q < NI * NK; ++q)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-  float bsum = 0.f;
-  const bool own = wv < ta_n;
-  // transposition IN PLACE of the block in ring slot `sl`: its (ta+tb) tiles are dealt to the 8 waves; a tile is read and
-  // rewritten by one wave only
-  auto transpose = [&](int sl) {
-    char* buf = lds + sl * WG_BUF_BYTES;
-    for (int tix = wv; tix < ntile; tix += 8) {
-      b8* tp = reinterpret_cast<b8*>(buf) + (tix * 2) * 64 + lane;
-      const b8 f0 = tp[0], f1 = tp[64];
-      facc t;
+  float bsum[NI];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) t[r] = 0.f;
-      if ((tix < ta_n ? type_a : type_b) == 0) {
-        t = MF<h8>::mma(__builtin_bit_cast(h8, f0), e0h, t);
-        t = MF<h8>::mma(__builtin_bit_cast(h8, f1), e1h, t);
-      } else {
-        t = MF<b8>::mma(f0, e0b, t);
-        t = MF<b8>::mma(f1, e1b, t);
-      }
-      b8 k0, k1;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { k0[j] = (__bf16)t[j]; k1[j] = (__bf16)t[8 + j]; }
-      tp[0] = k0;
-      tp[64] = k1;
-    }
-  };
-  // Ring of WG_DEPTH block buffers.  Software pipeline with ONE barrier per block: in the interval of block b the waves contract
-  // block b (transposed during the previous interval) and transpose block b+1 (its copy has landed), while the copies of blocks
-  // b+2 .. b+WG_DEPTH-1 are in flight.  Raw barriers + counted vmcnt throughout: __syncthreads() would drain the copies.
+  for (int i = 0; i < NI; ++i) bsum[i] = 0.f;
+  // Ring of WG_DEPTH block buffers, ONE barrier per block: it publishes block blk (every wave has waited for its own chunks) and
+  // frees the slot of block blk - 1, which the next copy then overwrites.  Raw barriers + counted vmcnt throughout:
+  // __syncthreads() would drain the copies in flight.
   for (int d = 0; d < WG_DEPTH - 1; ++d)
     if (b0 + d < b1) issue(b0 + d, d);
-  if (b0 < b1) {
-    long younger = b1 - 1 - b0;
-    if (younger > WG_DEPTH - 2) younger = WG_DEPTH - 2;
-    wait_vmcnt((int)younger * my_chunks);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    transpose(0);
-  }
   int slot = 0;
   for (long blk = b0; blk < b1; ++blk) {
-    // this wave's chunks of block blk+1 have landed when at most the chunks of the younger blocks in flight are outstanding
-    // (LDS-DMA completes in issue order)
-    long younger = b1 - 2 - blk;
-    if (younger > WG_DEPTH - 3) younger = WG_DEPTH - 3;
-    if (younger < 0) younger = 0;
+    // LDS-DMA completes in issue order: block blk has landed when at most the chunks of the younger blocks are outstanding
+    long younger = b1 - 1 - blk;
+    if (younger > WG_DEPTH - 2) younger = WG_DEPTH - 2;
     wait_vmcnt((int)younger * my_chunks);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my transposed tiles of block blk are written, my reads of block blk-1 are done
-    __builtin_amdgcn_s_barrier();                        // -> block blk is transposed, block blk+1 has landed, the slot of blk-1 is free
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of block blk - 1 are done
+    __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (blk + WG_DEPTH - 1 < b1) issue(blk + WG_DEPTH - 1, (slot + WG_DEPTH - 1) % WG_DEPTH);
-    if (own) {
-      const b8* L = reinterpret_cast<const b8*>(lds + slot * WG_BUF_BYTES) + lane;
-      const b8 a0 = L[(wv * 2) * 64], a1 = L[(wv * 2 + 1) * 64];
-      if (bias_partial) {
+    lds_char* buf = (lds_char*)(lds + slot * WG_BUF_BYTES) + lane_off;
+    b8 a[NI][2];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bsum += (float)a0[j] + (float)a1[j];
+    for (int i = 0; i < NI; ++i) {
+      const int ta = wa + WA * i;
+      if (ta < ta_n) {
+        a[i][0] = tr_frag(buf + ta * 2048, 0);
+        a[i][1] = tr_frag(buf + ta * 2048, 1);
       }
-      // the B fragments are requested in batches of WG_BATCH ahead of their MFMAs (hipcc otherwise emits read -> wait -> MFMA
-      // per fragment: 20 exposed LDS round trips per block); two batches keep the kernel clear of spills
-#ifndef WG_BATCH
-#define WG_BATCH 5
-#endif
+    }
+    b8 bv[NK][2];
 #pragma unroll
-      for (int q0 = 0; q0 < WG_TB_MAX; q0 += WG_BATCH) {
-        b8 bv[WG_BATCH][2];
+    for (int k = 0; k < NK; ++k) {
+      const int tb = wb + WB * k;
+      if (tb < tb_n) {
+        bv[k][0] = tr_frag(buf + (ta_n + tb) * 2048, 0);
+        bv[k][1] = tr_frag(buf + (ta_n + tb) * 2048, 1);
+      }
+    }
+    if (type_a == 0) {
 #pragma unroll
-        for (int k = 0; k < WG_BATCH; ++k) {
-          if (q0 + k < WG_TB_MAX && q0 + k < tb_n) {
-            bv[k][0] = L[((ta_n + q0 + k) * 2) * 64];
-            bv[k][1] = L[((ta_n + q0 + k) * 2 + 1) * 64];
-          }
+      for (int i = 0; i < NI; ++i) { a[i][0] = f16_to_bf16(a[i][0]); a[i][1] = f16_to_bf16(a[i][1]); }
+    }
+    if (type_b == 0) {
+#pragma unroll
+      for (int k = 0; k < NK; ++k) { bv[k][0] = f16_to_bf16(bv[k][0]); bv[k][1] = f16_to_bf16(bv[k][1]); }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      if (wa + WA * i < ta_n) {
+        if (bias_partial && wb == 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bsum[i] += (float)a[i][0][j] + (float)a[i][1][j];
         }
 #pragma unroll
-        for (int k = 0; k < WG_BATCH; ++k) asm volatile("" : "+v"(bv[k][0]), "+v"(bv[k][1]));
-#pragma unroll
-        for (int k = 0; k < WG_BATCH; ++k) {
-          if (q0 + k < WG_TB_MAX && q0 + k < tb_n) {
-            acc[q0 + k] = MF<b8>::mma(a0, bv[k][0], acc[q0 + k]);
-            acc[q0 + k] = MF<b8>::mma(a1, bv[k][1], acc[q0 + k]);
+        for (int k = 0; k < NK; ++k) {
+          if (wb + WB * k < tb_n) {
+            acc[i * NK + k] = MF<b8>::mma(a[i][0], bv[k][0], acc[i * NK + k]);
+            acc[i * NK + k] = MF<b8>::mma(a[i][1], bv[k][1], acc[i * NK + k]);
           }
         }
       }
     }
-    if (blk + 1 < b1) transpose((slot + 1) % WG_DEPTH);
     slot = (slot + 1) % WG_DEPTH;
   }
-  if (own) {
-    float* dst = partial + (long)split * out_elems;
+  float* dst = partial + (long)split * out_elems;
 #pragma unroll
-    for (int q = 0; q < WG_TB_MAX; ++q) {
-      if (q < tb_n) {
-        f4* d4 = reinterpret_cast<f4*>(dst + ((long)(wv * tb_n + q) * 64 + lane) * 16);
+  for (int i = 0; i < NI; ++i) {
+    const int ta = wa + WA * i;
+    if (ta >= ta_n) continue;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          f4 v; v[0] = acc[q][4 * k]; v[1] = acc[q][4 * k + 1]; v[2] = acc[q][4 * k + 2]; v[3] = acc[q][4 * k + 3];
-          d4[k] = v;
-        }
+    for (int k = 0; k < NK; ++k) {
+      const int tb = wb + WB * k;
+      if (tb >= tb_n) continue;
+      f4* d4 = reinterpret_cast<f4*>(dst + ((long)(ta * tb_n + tb) * 64 + lane) * 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f4 v;
+        v[0] = acc[i * NK + k][4 * q]; v[1] = acc[i * NK + k][4 * q + 1]; v[2] = acc[i * NK + k][4 * q + 2]; v[3] = acc[i * NK + k][4 * q + 3];
+        d4[q] = v;
       }
     }
-    if (bias_partial) {
-      bsum = xhalf_sum(bsum);
-      if (lane < 32) bias_partial[(long)split * bias_elems + wv * 32 + lane] = bsum;
+    if (bias_partial && wb == 0) {
+      const float s = xhalf_sum(bsum[i]);
+      if (lane < 32) bias_partial[(long)split * bias_elems + ta * 32 + lane] = s;
     }
   }
 }
@@ -197,8 +195,21 @@ __global__ __launch_bounds__(512) void weight_grad_all_kernel(const b8* __restri
                                                               int out_elems, int bias_elems) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int* d = pp.v[blockIdx.y];
-  weight_grad_body(lds, panels, ptiles, d[0], d[1], d[2], d[3], d[6], d[7], nblk, partial + d[4],
-                   d[5] >= 0 ? bias_partial + d[5] : nullptr, out_elems, bias_elems);
+  float* bp = d[5] >= 0 ? bias_partial + d[5] : nullptr;
+  // wide x wide: 2 x 4 (or 4 x 2) tiles per wave, the f16 operand on the side with fewer tiles per wave (it is converted to bf16
+  // after the read); narrow pairs: 8 x 1 or 1 x 8 waves
+#define WG_ARGS lds, panels, ptiles, d[0], d[1], d[2], d[3], d[6], d[7], nblk, partial + d[4], bp, out_elems, bias_elems
+  if (d[1] > 1 && d[3] > 2 && d[3] <= 8) {
+    if (d[7] == 0) weight_grad_body<4, 2>(WG_ARGS, 2);
+    else weight_grad_body<2, 4>(WG_ARGS, 4);
+  } else if (d[1] > 1 && d[3] > 8) {
+    weight_grad_body<2, 5>(WG_ARGS, 4);
+  } else if (d[1] > 1) {
+    weight_grad_body<1, 2>(WG_ARGS, 8);      // tb <= 2: one A tile x both B tiles per wave
+  } else {
+    weight_grad_body<1, 2>(WG_ARGS, 1);      // a single A tile: 1 x 8 waves, one (or two) B tiles each
+  }
+#undef WG_ARGS
 }
 
 extern "C" int avc_weight_grad_all(const void* panels, int ptiles, int npairs, const int* pairs, long nblk, float* partial,

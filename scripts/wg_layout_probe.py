@@ -1,0 +1,29 @@
+"""weight-gradient kernel per pair shape (development aid): each (ta, tb, type_a, type_b) of the real pair list alone over 4 Mi
+points of the real 180-tile panel: python scripts/wg_layout_probe.py"""
+import sys, os, ctypes, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from avatarclip_amd import lib as L
+lib = L.load()
+dev = torch.device("cuda")
+nblk = 1 << 17     # 4 Mi points
+st = torch.cuda.current_stream().cuda_stream
+nsplit = 256
+ptiles = 180
+panels = torch.zeros(nblk * ptiles * 1024, dtype=torch.int16, device=dev)
+out = torch.empty(nsplit, 4 * 72 * 1024, device=dev)
+bo = torch.empty(nsplit, 1024, device=dev)
+tot = 0.0
+for (ta, tb, tya, tyb, count) in ((8, 2, 1, 0, 2), (8, 2, 0, 1, 1), (8, 8, 1, 0, 3), (8, 8, 0, 1, 2), (7, 8, 1, 0, 1), (7, 8, 0, 1, 1), (8, 7, 1, 0, 1),
+                                  (1, 7, 1, 0, 1), (1, 2, 1, 0, 1), (1, 7, 1, 1, 1), (1, 2, 1, 1, 1), (8, 9, 1, 0, 1), (1, 8, 1, 0, 1)):
+    pairs = np.array([[0, ta, 20, tb, 0, -1, tya, tyb]], dtype=np.int32)
+    def run():
+        rc = lib.avc_weight_grad_all(panels.data_ptr(), ptiles, 1, pairs.ctypes.data, nblk, out.data_ptr(), bo.data_ptr(), nsplit, out.stride(0), bo.stride(0), st)
+        assert rc == 0
+    run(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); run(); e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    gb = nblk * (ta + tb) * 2048 / 1e9
+    tot += ms * count
+    print("ta %d tb %d types %d/%d  x%d: %.3f ms for %.2f GB of tiles: %.0f GB/s" % (ta, tb, tya, tyb, count, ms, gb, gb / ms * 1e3), flush=True)
+print("sum over the real pair list: %.3f ms" % tot)

@@ -13,14 +13,15 @@ import torch
 import torch.nn.functional as F
 
 from .clip_vit import CLIP_MEAN, CLIP_STD
+from . import h2d
 
 
 def preprocess_renders(images: torch.Tensor) -> torch.Tensor:
     """ShapeGen/main.py:104-106 and pose_generation.py:79-83: F.interpolate(images, size=224) (default mode: NEAREST) and
     the CLIP normalisation."""
     x = F.interpolate(images.float(), size=224)
-    mean = torch.tensor(CLIP_MEAN, device=x.device, dtype=x.dtype).view(1, 3, 1, 1)
-    std = torch.tensor(CLIP_STD, device=x.device, dtype=x.dtype).view(1, 3, 1, 1)
+    mean = h2d.const(CLIP_MEAN, x.device, x.dtype).view(1, 3, 1, 1)
+    std = h2d.const(CLIP_STD, x.device, x.dtype).view(1, 3, 1, 1)
     return (x - mean) / std
 
 

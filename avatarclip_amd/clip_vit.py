@@ -14,6 +14,7 @@ import torch
 import torch.nn.functional as F
 
 from . import lib as L
+from . import h2d
 
 WIDTH, LAYERS, HEADS, PATCH, RES, EMBED = 768, 12, 12, 32, 224, 512
 TOKENS = (RES // PATCH) ** 2 + 1
@@ -199,6 +200,6 @@ def clip_preprocess(img_hw3: torch.Tensor) -> torch.Tensor:
     x = img_hw3.permute(2, 0, 1).unsqueeze(0)
     if x.shape[-1] != RES or x.shape[-2] != RES:
         x = F.interpolate(x, size=(RES, RES), mode="bilinear", align_corners=False)
-    mean = torch.tensor(CLIP_MEAN, device=x.device, dtype=x.dtype).view(1, 3, 1, 1)
-    std = torch.tensor(CLIP_STD, device=x.device, dtype=x.dtype).view(1, 3, 1, 1)
+    mean = h2d.const(CLIP_MEAN, x.device, x.dtype).view(1, 3, 1, 1)
+    std = h2d.const(CLIP_STD, x.device, x.dtype).view(1, 3, 1, 1)
     return (x - mean) / std

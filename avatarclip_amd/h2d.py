@@ -1,0 +1,59 @@
+"""Host -> device uploads of the small per-iteration values (camera pose, light direction, ...) that do not stall the launch
+queue.  A `tensor.to(device)` from pageable memory is a blocking copy ordered behind everything already enqueued on the
+stream: one of them after the render kernels makes the host wait for the render and then launch the ~1000 small CLIP kernels
+with the GPU idling in between.  Here the values go through a ring of pinned staging rows (non-blocking copies; a row is
+reused only after the event recorded behind its copy has completed) and constants are uploaded once per device."""
+import numpy as np
+import torch
+
+_consts = {}
+_rings = {}
+
+
+def const(values, device, dtype=torch.float32):
+    """a constant tensor (cached per device): CLIP mean / std, the camera up vector, ..."""
+    a = np.asarray(values, np.float64)
+    key = (a.tobytes(), a.shape, str(device), dtype)
+    t = _consts.get(key)
+    if t is None:
+        t = torch.tensor(a.tolist(), dtype=dtype, device=device)
+        _consts[key] = t
+    return t
+
+
+class _Ring:
+    SLOTS, WIDTH = 64, 64   # rows of 64 doubles (512 B): poses, eyes, directions
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = torch.empty(self.SLOTS, self.WIDTH, dtype=torch.float64).pin_memory()
+        self.events = [None] * self.SLOTS
+        self.i = 0
+
+    def put(self, a, dtype):
+        n = a.size
+        slot = self.i % self.SLOTS
+        self.i += 1
+        ev = self.events[slot]
+        if ev is not None:
+            ev.synchronize()
+        row = self.buf[slot, :n]
+        row.copy_(torch.from_numpy(a.reshape(-1)))
+        out = row.to(self.device, non_blocking=True).to(dtype).reshape(a.shape)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[slot] = ev
+        return out
+
+
+def upload(values, device, dtype=torch.float32):
+    """values (array-like of <= 64 numbers) -> device tensor of `dtype` without blocking the host on the stream."""
+    a = np.ascontiguousarray(np.asarray(values, np.float64))
+    device = torch.device(device)
+    if device.type != "cuda" or a.size > _Ring.WIDTH:
+        return torch.from_numpy(a).to(device=device, dtype=dtype)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    ring = _rings.get(key)
+    if ring is None:
+        ring = _rings[key] = _Ring(device)
+    return ring.put(a, dtype)

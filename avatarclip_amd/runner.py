@@ -29,6 +29,7 @@ from .fields import RenderingNetwork, SDFNetwork, SingleVarianceNetwork
 from .renderer import NeuSRenderer
 from .utils import lookat, random_at, random_eye, random_eye_normal, sphere_coord
 from . import parallel
+from . import h2d
 
 
 class EllipsoidPrior:
@@ -334,7 +335,7 @@ class Runner:
     def make_view(self, iter_i, camera=None):
         dev = self.device
         eye, at, theta, phi, is_front = camera if camera is not None else self.sample_camera(iter_i)
-        pose = torch.from_numpy(lookat(eye, at, np.array([0, 1, 0]))).float().to(dev)
+        pose = h2d.upload(lookat(eye, at, np.array([0, 1, 0])), dev)
         prior = self.prior_renderer(eye, at)
         true_rgb = torch.as_tensor(prior, dtype=torch.float32, device=dev)
         ori_mask = (true_rgb != 0).float()[..., 0]
@@ -393,7 +394,7 @@ class Runner:
                                          view.phi + np.random.uniform(-np.pi / 4, np.pi / 4))
             else:
                 light_dir = np.asarray(light[0])
-            rand_light_d = torch.zeros_like(normals) + torch.from_numpy(np.asarray(light_dir)).float().to(dev)
+            rand_light_d = torch.zeros_like(normals) + h2d.upload(np.asarray(light_dir), dev)
             rand_light_d = rand_light_d / (torch.norm(rand_light_d, dim=-1, keepdim=True) + 1e-7)
             rand_diffuse_shading = (normals * rand_light_d).sum(-1, keepdim=True).clamp(min=0, max=1)
             rand_diffuse_shading = torch.where(torch.isnan(rand_diffuse_shading), torch.ones_like(rand_diffuse_shading), rand_diffuse_shading)

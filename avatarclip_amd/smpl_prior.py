@@ -10,6 +10,7 @@ import numpy as np
 import torch
 
 from . import lib as L
+from . import h2d
 
 ROT_MAT = ((1.0, 0.0, 0.0), (0.0, 0.0, -1.0), (0.0, 1.0, 0.0))    # models/utils.py:114-118
 
@@ -73,10 +74,10 @@ class MeshPrior:
     def render_grey(self, eye, direction):
         """nr.Renderer(camera_mode='look')(vertices, faces, ones) -> [S,S] grey image (before the x flip)"""
         dev = self.device
-        eye = torch.as_tensor(np.asarray(eye, np.float32)).to(dev)
-        z = torch.as_tensor(np.asarray(direction, np.float32)).to(dev)
+        eye = h2d.upload(np.asarray(eye, np.float32), dev)
+        z = h2d.upload(np.asarray(direction, np.float32), dev)
         z = z / z.norm()
-        up = torch.tensor([0.0, 1.0, 0.0], device=dev)
+        up = h2d.const([0.0, 1.0, 0.0], dev)
         x = torch.linalg.cross(up, z)
         x = x / x.norm()
         y = torch.linalg.cross(z, x)

@@ -170,6 +170,7 @@ def main():
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--small", action="store_true", help="128-wide nets (confs/examples_small)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-debug", action="store_true", help="development aid: warn (with a stack) on every host-device synchronisation inside the timed steps")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -223,9 +224,13 @@ def main():
     Engine.prof_events = []
     parallel.barrier()
     torch.cuda.synchronize()
+    if args.sync_debug:
+        torch.cuda.set_sync_debug_mode("warn")
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    if args.sync_debug:
+        torch.cuda.set_sync_debug_mode("default")
     torch.cuda.synchronize()
     parallel.barrier()
     dt = time.perf_counter() - t0

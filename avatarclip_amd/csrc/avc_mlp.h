@@ -270,15 +270,17 @@ __device__ __forceinline__ void layer2_s(ST& st, const V* __restrict__ blob, int
 template <class N>
 struct PanelLayout {
   static constexpr int HT = N::HT, ST = N::ST, NM = N::NMID, NC = N::NCMID;
-  static constexpr int P_H0 = 0;                    // pe values (2 tiles)                         f16, forward
-  static constexpr int P_GB0 = P_H0 + 2;            // gbar_h0 (2)                                 bf16, backward
-  static constexpr int P_H1 = P_GB0 + 2;            // h1                                          f16, forward
+  // (hs, pe) and (gbar_hs, gbar_h0) are adjacent: the last layer's input is [hs | pe], so its weight-gradient products read
+  // them as ONE run of ST + 2 tiles
+  static constexpr int P_H1 = 0;                    // h1                                          f16, forward
   static constexpr int P_HM = P_H1 + HT;            // hm[NM]
   static constexpr int P_HS = P_HM + NM * HT;       // hs (ST)
-  static constexpr int P_GBH1 = P_HS + ST;          // gbar_h1                                     bf16, backward
+  static constexpr int P_H0 = P_HS + ST;            // pe values (2 tiles)
+  static constexpr int P_GBH1 = P_H0 + 2;           // gbar_h1                                     bf16, backward
   static constexpr int P_GBHM = P_GBH1 + HT;        // gbar_hm[NM]
   static constexpr int P_GBHS = P_GBHM + NM * HT;   // gbar_hs (ST)
-  static constexpr int P_GA1 = P_GBHS + ST;         // g_a1                                        f16, forward
+  static constexpr int P_GB0 = P_GBHS + ST;         // gbar_h0 (2)
+  static constexpr int P_GA1 = P_GB0 + 2;           // g_a1                                        f16, forward
   static constexpr int P_GAM = P_GA1 + HT;          // g_am[NM]
   static constexpr int P_GAS = P_GAM + NM * HT;     // g_as (ST)
   static constexpr int P_AB1 = P_GAS + ST;          // abar_1                                      bf16, backward

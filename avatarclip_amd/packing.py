@@ -328,8 +328,8 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
     # forward-type operands are written by the forward kernel as f16 tiles, gradient-type operands by the backward kernel as bf16
     F16_PANELS = ("H0", "H1", "HM", "HS", "GA1", "GAM", "GAS", "FEAT", "XN", "R1", "R2")
     tile_type = []
-    for name, nt in [("H0", 2), ("GB0", 2), ("H1", HT), ("HM", NMID * HT), ("HS", ST), ("GBH1", HT),
-                     ("GBHM", NMID * HT), ("GBHS", ST), ("GA1", HT), ("GAM", NMID * HT), ("GAS", ST), ("AB1", HT),
+    for name, nt in [("H1", HT), ("HM", NMID * HT), ("HS", ST), ("H0", 2), ("GBH1", HT),
+                     ("GBHM", NMID * HT), ("GBHS", ST), ("GB0", 2), ("GA1", HT), ("GAM", NMID * HT), ("GAS", ST), ("AB1", HT),
                      ("ABM", NMID * HT), ("ABS", ST), ("DFEAT", HT), ("SDF", 1), ("ONE", 1), ("FEAT", HT), ("XN", 1),
                      ("R1", HT), ("R2", NCMID * HT), ("D1", HT), ("D2", NCMID * HT), ("DO", 1)]:
         P[name] = c
@@ -372,6 +372,7 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
                         ub_tgt.append(pbase[bname] + row)
             gbias[0] += 32 * ta
         ld = shp[wname][1]
+        scale_of = scale if callable(scale) else (lambda t_b: scale)
         rows_of = np.array([[[rowmap(32 * t + acc_row(r, h)) for r in range(16)] for h in range(2)] for t in range(ta)])
         cols_of = np.array([[colmap(32 * t + nn) for nn in range(32)] for t in range(tb)])
         for t_a in range(ta):
@@ -389,7 +390,7 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
                     src = base + lane * 16 + np.nonzero(ok)[0]
                     un_src.append(src)
                     un_tgt.append(pbase[wname] + rws[ok] * ld + col)
-                    un_scale.append(np.full(len(src), scale, np.float32))
+                    un_scale.append(np.full(len(src), scale_of(t_b), np.float32))
         assert len({panel_type(pa + t) for t in range(ta)}) == 1 and len({panel_type(pb + t) for t in range(tb)}) == 1
         pairs.append((pa, ta, pb, tb, out_off, bias_off, panel_type(pa), panel_type(pb)))
         gout[0] += ta * tb * 64 * 16
@@ -410,12 +411,16 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
     # last layer: rows 1..H (ybar[1:]) and row 0 (d_sdf ; second-order term through the constant-one panel)
     r1 = lambda f: (f + 1) if f < H else -1
     r0 = lambda f: 0 if f == 0 else -1
-    add_pair(P["DFEAT"], HT, P["HS"], ST, ll, r1, feat_std(SKIP), scale=1 / (SQ2 * S_B2), bname=bl)
-    add_pair(P["DFEAT"], HT, P["H0"], 2, ll, r1, feat_pe(True, shift=SKIP), scale=1 / SQ2)
-    add_pair(P["SDF"], 1, P["HS"], ST, ll, r0, feat_std(SKIP), scale=1 / (SQ2 * S_B2), bname=bl)
-    add_pair(P["SDF"], 1, P["H0"], 2, ll, r0, feat_pe(True, shift=SKIP), scale=1 / SQ2)
-    add_pair(P["ONE"], 1, P["GBHS"], ST, ll, r0, feat_std(SKIP), scale=1 / SQ2)
-    add_pair(P["ONE"], 1, P["GB0"], 2, ll, r0, feat_pe(False, shift=SKIP), scale=1 / SQ2)
+    # (its input [hs | pe] = the adjacent panels HS, H0 resp. GBHS, GB0: one product over ST + 2 column tiles each)
+    assert P["H0"] == P["HS"] + ST and P["GB0"] == P["GBHS"] + ST
+
+    def last_cols(lo_as_x):
+        a, b = feat_std(SKIP), feat_pe(lo_as_x, shift=SKIP)
+        return lambda f: a(f) if f < 32 * ST else b(f - 32 * ST)
+    hs_scale = lambda t_b: 1 / (SQ2 * S_B2) if t_b < ST else 1 / SQ2
+    add_pair(P["DFEAT"], HT, P["HS"], ST + 2, ll, r1, last_cols(True), scale=hs_scale, bname=bl)
+    add_pair(P["SDF"], 1, P["HS"], ST + 2, ll, r0, last_cols(True), scale=hs_scale, bname=bl)
+    add_pair(P["ONE"], 1, P["GBHS"], ST + 2, ll, r0, last_cols(False), scale=1 / SQ2)
     # colour
     fx = feat_xn()
     c0col = lambda f: (6 + f) if f < H else fx(f - H)

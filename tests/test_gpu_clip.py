@@ -72,3 +72,96 @@ def test_encode_image_matches_oracle():
     assert sim.min() > 0.9995
     assert abs(cos.item() - cos_r.item()) < 1e-3
     assert rel < 3e-2
+
+
+def _full_state_dict():
+    from oracle import clip_text_oracle as T
+    sd = dict(C.random_state_dict(0))
+    sd.update(T.random_state_dict(1))
+    return sd
+
+
+def test_checkpoint_file_formats_load_to_the_same_state_dict(tmp_path):
+    """clip_vit.load_state_dict (the $AVC_CLIP_WEIGHTS / clip.weights hook): a torch.save()d state dict, a .safetensors file and a
+    TorchScript archive (the format of OpenAI's ViT-B-32.pt) all give back the tensors that went in"""
+    from safetensors.torch import save_file
+    from avatarclip_amd import clip_vit as V
+    sd = {k: v for k, v in _full_state_dict().items() if k.startswith("visual.ln_") or k.startswith("ln_final") or k == "logit_scale"
+          or k.endswith("resblocks.0.ln_1.weight")}
+    assert len(sd) >= 4
+    torch.save(sd, tmp_path / "w.pt")
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(tmp_path / "w.safetensors"))
+
+    class Holder(torch.nn.Module):          # a scripted module whose state dict carries the same names
+        def __init__(self):
+            super().__init__()
+            for i, (k, v) in enumerate(sorted(sd.items())):
+                self.register_buffer("b%d" % i, v.clone())
+
+        def forward(self, x):
+            return x
+    torch.jit.script(Holder()).save(str(tmp_path / "w_script.pt"))
+    a = V.load_state_dict(str(tmp_path / "w.pt"))
+    b = V.load_state_dict(str(tmp_path / "w.safetensors"))
+    c = V.load_state_dict(str(tmp_path / "w_script.pt"))
+    assert set(a) == set(b) == set(sd)
+    for k in sd:
+        assert torch.equal(a[k], sd[k]) and torch.equal(b[k], sd[k])
+    assert len(c) == len(sd) and all(torch.equal(c["b%d" % i], v) for i, (k, v) in enumerate(sorted(sd.items())))
+
+
+@gpu
+def test_runner_takes_clip_weights_from_a_checkpoint_file_without_standins(tmp_path, monkeypatch):
+    """main.py:258-259 (`clip.load('ViT-B/32')`): with $AVC_CLIP_WEIGHTS pointing at a checkpoint the Runner needs no stand-in for
+    the perceptor (allow_standins = False would raise otherwise) and its image embeddings are the oracle's on that state dict"""
+    import bench
+    from avatarclip_amd.runner import Runner
+    sd = _full_state_dict()
+    torch.save(sd, tmp_path / "ViT-B-32.pt")
+    monkeypatch.setenv("AVC_CLIP_WEIGHTS", str(tmp_path / "ViT-B-32.pt"))
+    conf = bench.make_conf(32, 32, small=True)
+    conf.put("general.allow_standins", False)
+    runner = Runner(None, mode="train_clip", conf=conf, device=torch.device("cuda"))
+    g = torch.Generator().manual_seed(3)
+    te = {k: torch.nn.functional.normalize(torch.randn(1, 512, generator=g), dim=-1) for k in ("prompt", "face_prompt", "back_prompt")}
+    runner.init_clip(text_embeddings=te)              # prompts cached; the perceptor comes from the file
+    img = torch.rand(1, 3, 224, 224, generator=g)
+    emb = runner.perceptor.encode_image(img.cuda()).float().cpu()
+    ref = C.encode_image(sd, img)
+    assert torch.cosine_similarity(emb, ref, dim=-1).min() > 0.9995
+    # without the file and without permission for stand-ins the set-up must refuse
+    monkeypatch.delenv("AVC_CLIP_WEIGHTS")
+    runner2 = Runner(None, mode="train_clip", conf=conf, device=torch.device("cuda"))
+    with pytest.raises(RuntimeError):
+        runner2.init_clip(text_embeddings=te)
+
+
+@gpu
+def test_real_openai_weights_when_supplied():
+    """Runs only where the licensed artefacts exist: $AVC_CLIP_WEIGHTS = OpenAI's ViT-B-32.pt (or a state-dict / safetensors copy)
+    and $AVC_CLIP_BPE = bpe_simple_vocab_16e6.txt.gz.  HIP encoders vs the fp32 oracle ON THE REAL WEIGHTS (the seeded-weight tests
+    above cannot show the dynamic range of trained weights), and the tokenizer against the known ids of CLIP's README example."""
+    import os
+    wpath, bpath = os.environ.get("AVC_CLIP_WEIGHTS"), os.environ.get("AVC_CLIP_BPE")
+    if not wpath or not os.path.exists(wpath):
+        pytest.skip("$AVC_CLIP_WEIGHTS not set: no real CLIP checkpoint on this machine")
+    from oracle import clip_text_oracle as T
+    from avatarclip_amd import clip_vit as V
+    sd = {k: v.float() for k, v in V.load_state_dict(wpath).items()}
+    model = V.ClipVisionB32(sd, torch.device("cuda"))
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(2, 3, 224, 224, generator=g)
+    emb = model.encode_image(img.cuda()).float().cpu()
+    ref = C.encode_image(sd, img)
+    assert torch.cosine_similarity(emb, ref, dim=-1).min() > 0.999
+    if bpath and os.path.exists(bpath):
+        from avatarclip_amd import tokenizer as TK
+        tk = TK.SimpleTokenizer(bpath)
+        tok = TK.tokenize(["a diagram", "a 3D rendering of the Iron Man in unreal engine"], tk)
+        assert tok[0, 0].item() == 49406 and tok[0, 1].item() == 320 and tok[0, 3].item() == 49407 and tok[0, 4:].sum().item() == 0
+        out = model.encode_text(tok).float().cpu()
+        ref_t = T.encode_text(sd, tok)
+        assert torch.cosine_similarity(out, ref_t, dim=-1).min() > 0.999
+        # a render prompt and an unrelated one must be told apart by the joint embedding the way CLIP does it: cos in (-1, 1), finite
+        cs = torch.cosine_similarity(out[0], out[1], dim=0)
+        assert torch.isfinite(cs) and cs < 0.99

@@ -90,6 +90,10 @@ __device__ __forceinline__ Next no_next() { Next n; n.ptr = nullptr; n.chunks = 
 // second wave back by about half a tile step lets one wave's epilogue run under the other's MFMA chain.
 #ifdef AVC_ABL_NOSYNC   // timing ablation only
 #define AVC_SYNC() do {} while (0)
+#elif defined(AVC_EXP_SYNC)   // timing experiment only (results are garbage): group barrier that leaves AVC_EXP_SYNC VMEM ops in flight
+#define AVC_STR2(x) #x
+#define AVC_STR(x) AVC_STR2(x)
+#define AVC_SYNC() do { asm volatile("s_waitcnt vmcnt(" AVC_STR(AVC_EXP_SYNC) ") lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 #else
 #define AVC_SYNC() __syncthreads()
 #endif

@@ -127,54 +127,63 @@ extern "C" int avc_vit_linear(const float* x, const void* w_packed, const float*
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// attention: qkv [B,T,3*W] (q | k | v, head hd at column hd*64), out [B,T,W].  One 64-thread workgroup per (b, head).
+// attention: qkv [B,T,3*W] (q | k | v, head hd at column hd*64), out [B,T,W].  One 4-wave workgroup per (b, head).
 // ---------------------------------------------------------------------------------------------------------
 #define AT_T 50
 #define AT_D 64
 #define AT_LD 65   // +1 padding: thread i reads row i -> conflict-free
 
-__global__ __launch_bounds__(64) void vit_attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, int Wd,
-                                                          int heads, float scale) {
-  __shared__ float Ks[AT_T][AT_LD], Vs[AT_T][AT_LD];
+// 4 wavefronts per (b, head): wave `part` owns the keys j = part (mod 4) for the scores and the 16 output columns
+// 16 part .. 16 part + 15 for P V; every LDS read of K / V is a broadcast (a wave shares j), P rows are stride-51 (conflict-free)
+#define AT_PARTS 4
+__global__ __launch_bounds__(64 * AT_PARTS) void vit_attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, int Wd,
+                                                                     int heads, float scale) {
+  __shared__ float Ks[AT_T][AT_LD], Vs[AT_T][AT_LD], Ps[AT_T][AT_T + 1], red[2][AT_PARTS][64];
   const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
-  const int i = threadIdx.x;
+  const int i = threadIdx.x & 63, part = threadIdx.x >> 6;
   const float* base = qkv + (long)b * AT_T * 3 * Wd + hd * AT_D;
-  for (int e = threadIdx.x; e < AT_T * AT_D; e += 64) {
+  for (int e = threadIdx.x; e < AT_T * AT_D; e += 64 * AT_PARTS) {
     const int r = e / AT_D, c = e % AT_D;
     Ks[r][c] = base[(long)r * 3 * Wd + Wd + c];
     Vs[r][c] = base[(long)r * 3 * Wd + 2 * Wd + c];
   }
   __syncthreads();
-  if (i >= AT_T) return;
-  float q[AT_D];
-#pragma unroll
-  for (int c = 0; c < AT_D; ++c) q[c] = base[(long)i * 3 * Wd + c] * scale;
-  float p[AT_T];
+  const bool live = i < AT_T;
   float mx = -1e30f;
+  if (live) {
+    float q[AT_D];
 #pragma unroll
-  for (int j = 0; j < AT_T; ++j) {
-    float s = 0.f;
+    for (int c = 0; c < AT_D; ++c) q[c] = base[(long)i * 3 * Wd + c] * scale;
+    for (int j = part; j < AT_T; j += AT_PARTS) {
+      float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < AT_D; ++c) s += q[c] * Ks[j][c];
-    p[j] = s;
-    mx = fmaxf(mx, s);
+      for (int c = 0; c < AT_D; ++c) s += q[c] * Ks[j][c];
+      Ps[i][j] = s;
+      mx = fmaxf(mx, s);
+    }
   }
+  red[0][part][i] = mx;
+  __syncthreads();
   float sum = 0.f;
-#pragma unroll
-  for (int j = 0; j < AT_T; ++j) { p[j] = __expf(p[j] - mx); sum += p[j]; }
-  const float inv = 1.f / sum;
-  float o[AT_D];
-#pragma unroll
-  for (int c = 0; c < AT_D; ++c) o[c] = 0.f;
-#pragma unroll
-  for (int j = 0; j < AT_T; ++j) {
-    const float pj = p[j] * inv;
-#pragma unroll
-    for (int c = 0; c < AT_D; ++c) o[c] += pj * Vs[j][c];
+  if (live) {
+    mx = fmaxf(fmaxf(red[0][0][i], red[0][1][i]), fmaxf(red[0][2][i], red[0][3][i]));
+    for (int j = part; j < AT_T; j += AT_PARTS) { const float e = __expf(Ps[i][j] - mx); Ps[i][j] = e; sum += e; }
   }
-  float* op = out + ((long)b * AT_T + i) * Wd + hd * AT_D;
+  red[1][part][i] = sum;
+  __syncthreads();
+  if (!live) return;
+  const float inv = 1.f / (red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i]);
+  float o[16];
 #pragma unroll
-  for (int c = 0; c < AT_D; ++c) op[c] = o[c];
+  for (int c = 0; c < 16; ++c) o[c] = 0.f;
+  for (int j = 0; j < AT_T; ++j) {
+    const float pj = Ps[i][j] * inv;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) o[c] += pj * Vs[j][16 * part + c];
+  }
+  float* op = out + ((long)b * AT_T + i) * Wd + hd * AT_D + 16 * part;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) op[c] = o[c];
 }
 
 // Text tower (clip/model.py encode_text: 77 tokens, 8 heads of 64, causal mask): forward only -- prompts are encoded once per
@@ -217,8 +226,8 @@ __global__ __launch_bounds__(TA_TMAX) void text_attn_fwd_kernel(const float* __r
   for (int c = 0; c < AT_D; ++c) op[c] = o[c] * inv;
 }
 
-__global__ __launch_bounds__(64) void vit_attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
-                                                          float* __restrict__ dqkv, int Wd, int heads, float scale) {
+__global__ __launch_bounds__(64 * AT_PARTS) void vit_attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                     float* __restrict__ dqkv, int Wd, int heads, float scale) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float (*Ks)[AT_LD] = reinterpret_cast<float (*)[AT_LD]>(sm);
   float (*Vs)[AT_LD] = Ks + AT_T;
@@ -226,11 +235,13 @@ __global__ __launch_bounds__(64) void vit_attn_bwd_kernel(const float* __restric
   float (*Ds)[AT_LD] = Qs + AT_T;                       // dO
   float (*Ps)[AT_T + 1] = reinterpret_cast<float (*)[AT_T + 1]>(Ds + AT_T);   // P
   float (*Ss)[AT_T + 1] = Ps + AT_T;                    // dS (already scaled)
+  float (*red)[AT_PARTS][64] = reinterpret_cast<float (*)[AT_PARTS][64]>(Ss + AT_T);   // [3][parts][64]: max, sum, sum p d
   const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
-  const int i = threadIdx.x;
+  const int i = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const bool live = i < AT_T;
   const float* base = qkv + (long)b * AT_T * 3 * Wd + hd * AT_D;
   const float* dob = dout + (long)b * AT_T * Wd + hd * AT_D;
-  for (int e = threadIdx.x; e < AT_T * AT_D; e += 64) {
+  for (int e = threadIdx.x; e < AT_T * AT_D; e += 64 * AT_PARTS) {
     const int r = e / AT_D, c = e % AT_D;
     Qs[r][c] = base[(long)r * 3 * Wd + c];
     Ks[r][c] = base[(long)r * 3 * Wd + Wd + c];
@@ -238,64 +249,68 @@ __global__ __launch_bounds__(64) void vit_attn_bwd_kernel(const float* __restric
     Ds[r][c] = dob[(long)r * Wd + c];
   }
   __syncthreads();
-  if (i < AT_T) {
-    // row i of P and dS lives in this thread's own LDS row (no register arrays with run-time indices)
-    float mx = -1e30f;
-    for (int j = 0; j < AT_T; ++j) {
-      float s = 0.f;
+  // scores and dP = dO V^T for the keys of this wave
+  float mx = -1e30f;
+  if (live) {
+    for (int j = part; j < AT_T; j += AT_PARTS) {
+      float s = 0.f, d = 0.f;
 #pragma unroll
-      for (int c = 0; c < AT_D; ++c) s += Qs[i][c] * Ks[j][c];
+      for (int c = 0; c < AT_D; ++c) { s += Qs[i][c] * Ks[j][c]; d += Ds[i][c] * Vs[j][c]; }
       s *= scale;
       Ps[i][j] = s;
+      Ss[i][j] = d;
       mx = fmaxf(mx, s);
     }
-    float sum = 0.f;
-    for (int j = 0; j < AT_T; ++j) { const float e = __expf(Ps[i][j] - mx); Ps[i][j] = e; sum += e; }
-    const float inv = 1.f / sum;
-    float dsum = 0.f;
-    for (int j = 0; j < AT_T; ++j) {
+  }
+  red[0][part][i] = mx;
+  __syncthreads();
+  float sum = 0.f;
+  if (live) {
+    mx = fmaxf(fmaxf(red[0][0][i], red[0][1][i]), fmaxf(red[0][2][i], red[0][3][i]));
+    for (int j = part; j < AT_T; j += AT_PARTS) { const float e = __expf(Ps[i][j] - mx); Ps[i][j] = e; sum += e; }
+  }
+  red[1][part][i] = sum;
+  __syncthreads();
+  float dsum = 0.f;
+  if (live) {
+    const float inv = 1.f / (red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i]);
+    for (int j = part; j < AT_T; j += AT_PARTS) {
       const float pj = Ps[i][j] * inv;
       Ps[i][j] = pj;
-      float d = 0.f;
-#pragma unroll
-      for (int c = 0; c < AT_D; ++c) d += Ds[i][c] * Vs[j][c];
-      Ss[i][j] = d;
-      dsum += pj * d;
+      dsum += pj * Ss[i][j];
     }
-    float dq[AT_D];
-#pragma unroll
-    for (int c = 0; c < AT_D; ++c) dq[c] = 0.f;
-    for (int j = 0; j < AT_T; ++j) {
-      const float ds = Ps[i][j] * (Ss[i][j] - dsum) * scale;
-      Ss[i][j] = ds;
-#pragma unroll
-      for (int c = 0; c < AT_D; ++c) dq[c] += ds * Ks[j][c];
-    }
-    float* dqp = dqkv + ((long)b * AT_T + i) * 3 * Wd + hd * AT_D;
-#pragma unroll
-    for (int c = 0; c < AT_D; ++c) dqp[c] = dq[c];
+  }
+  red[2][part][i] = dsum;
+  __syncthreads();
+  if (live) {
+    dsum = red[2][0][i] + red[2][1][i] + red[2][2][i] + red[2][3][i];
+    for (int j = part; j < AT_T; j += AT_PARTS) Ss[i][j] = Ps[i][j] * (Ss[i][j] - dsum) * scale;
   }
   __syncthreads();
-  if (i < AT_T) {
-    const int j = i;
-    float dk[AT_D], dv[AT_D];
+  if (!live) return;
+  // dQ row i, dK / dV row j = i: this wave's 16 columns
+  const int c0 = 16 * part;
+  float dq[16], dk[16], dv[16];
 #pragma unroll
-    for (int c = 0; c < AT_D; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
-    for (int r = 0; r < AT_T; ++r) {
-      const float ds = Ss[r][j], pr = Ps[r][j];
+  for (int c = 0; c < 16; ++c) { dq[c] = 0.f; dk[c] = 0.f; dv[c] = 0.f; }
+  for (int r = 0; r < AT_T; ++r) {
+    const float ds_q = Ss[i][r];
+    const float ds_k = Ss[r][i], pr = Ps[r][i];
 #pragma unroll
-      for (int c = 0; c < AT_D; ++c) { dk[c] += ds * Qs[r][c]; dv[c] += pr * Ds[r][c]; }
+    for (int c = 0; c < 16; ++c) {
+      dq[c] += ds_q * Ks[r][c0 + c];
+      dk[c] += ds_k * Qs[r][c0 + c];
+      dv[c] += pr * Ds[r][c0 + c];
     }
-    float* dkp = dqkv + ((long)b * AT_T + j) * 3 * Wd + Wd + hd * AT_D;
-    float* dvp = dqkv + ((long)b * AT_T + j) * 3 * Wd + 2 * Wd + hd * AT_D;
-#pragma unroll
-    for (int c = 0; c < AT_D; ++c) { dkp[c] = dk[c]; dvp[c] = dv[c]; }
   }
+  float* dqp = dqkv + ((long)b * AT_T + i) * 3 * Wd + hd * AT_D + c0;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) { dqp[c] = dq[c]; dqp[Wd + c] = dk[c]; dqp[2 * Wd + c] = dv[c]; }
 }
 
 extern "C" int avc_vit_attention_fwd(const float* qkv, float* out, int B, int T, int width, int heads, void* stream) {
   if (T != AT_T || width != heads * AT_D) { avc_set_error("avc_vit_attention: built for 50 tokens, head dim 64"); return 1; }
-  hipLaunchKernelGGL(vit_attn_fwd_kernel, dim3(B * heads), dim3(64), 0, (hipStream_t)stream, qkv, out, width, heads, 0.125f);
+  hipLaunchKernelGGL(vit_attn_fwd_kernel, dim3(B * heads), dim3(64 * AT_PARTS), 0, (hipStream_t)stream, qkv, out, width, heads, 0.125f);
   return avc_check_launch("avc_vit_attention_fwd");
 }
 extern "C" int avc_text_attention_fwd(const float* qkv, float* out, int B, int T, int width, int heads, int causal, void* stream) {
@@ -314,13 +329,13 @@ extern "C" int avc_text_attention_fwd(const float* qkv, float* out, int B, int T
 extern "C" int avc_vit_attention_bwd(const float* qkv, const float* dout, float* dqkv, int B, int T, int width, int heads,
                                      void* stream) {
   if (T != AT_T || width != heads * AT_D) { avc_set_error("avc_vit_attention: built for 50 tokens, head dim 64"); return 1; }
-  const size_t lds = (4 * AT_T * AT_LD + 2 * AT_T * (AT_T + 1)) * sizeof(float);
+  const size_t lds = (4 * AT_T * AT_LD + 2 * AT_T * (AT_T + 1) + 3 * AT_PARTS * 64) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)vit_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(vit_attn_bwd_kernel, dim3(B * heads), dim3(64), lds, (hipStream_t)stream, qkv, dout, dqkv, width, heads,
+  hipLaunchKernelGGL(vit_attn_bwd_kernel, dim3(B * heads), dim3(64 * AT_PARTS), lds, (hipStream_t)stream, qkv, dout, dqkv, width, heads,
                      0.125f);
   return avc_check_launch("avc_vit_attention_bwd");
 }

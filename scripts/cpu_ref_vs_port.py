@@ -48,17 +48,25 @@ for side, iters in ((64, 2), (224, 1)):
         opt = torch.optim.Adam(params, lr=5e-4)
         ren = R.NeuSRenderer(None, sdf, var, col, 32, 32, 0, 4, 1.0, extra_color=True)
         ts = []
+        # 224 x 224 x 64 spp does not fit the 62 GB of the build container in one autograd graph: 8 ray chunks with accumulated
+        # gradients on both legs (the arithmetic per ray is unchanged)
+        nchunk = 1 if side == 64 else 8
         for it in range(iters + (1 if side == 64 else 0)):
             torch.manual_seed(100 + it)                 # the reference draws its jitter with torch.rand inside render()
             t0 = time.time()
-            if leg.startswith("reference"):
-                out = ren.render(ro, rd, near, far, background_rgb=torch.zeros(1, 3), cos_anneal_ratio=1.0)
-            else:
-                jitter = torch.rand(Rn, 1)
-                out = O.render(dict(sdf.named_parameters()), dict(col.named_parameters()), var.variance, ro, rd, near, far, 32, 32, 4,
-                               jitter, torch.zeros(1, 3), 1.0)
-            loss = loss_of(out, Rn)
-            opt.zero_grad(); loss.backward(); opt.step()
+            opt.zero_grad()
+            for c in range(nchunk):
+                sl = slice(c * Rn // nchunk, (c + 1) * Rn // nchunk)
+                n = sl.stop - sl.start
+                if leg.startswith("reference"):
+                    out = ren.render(ro[sl], rd[sl], near[sl], far[sl], background_rgb=torch.zeros(1, 3), cos_anneal_ratio=1.0)
+                else:
+                    jitter = torch.rand(n, 1)
+                    out = O.render(dict(sdf.named_parameters()), dict(col.named_parameters()), var.variance, ro[sl], rd[sl], near[sl], far[sl],
+                                   32, 32, 4, jitter, torch.zeros(1, 3), 1.0)
+                loss = loss_of(out, n) / nchunk
+                loss.backward()
+            opt.step()
             ts.append(time.time() - t0)
         t = float(np.mean(ts[1:])) if len(ts) > 1 else ts[0]
         print("| %d (%dx%d) | %s | %.2f | %.0f | %d | %.6f |" % (Rn, side, side, leg, t, Rn / t, nthreads, loss.item()), flush=True)

@@ -40,7 +40,7 @@ class ClipTextB32:
 
     @staticmethod
     def _lin(x2d, lin, act=0, residual=None):
-        y, _ = _linear_raw(x2d, lin.wp, lin.b, residual, lin.N, lin.K, act, False)
+        y, _ = _linear_raw(x2d, lin, False, lin.b, residual, act, False)
         return y
 
     @torch.no_grad()

@@ -36,6 +36,7 @@ class _Lin:
         self.N, self.K = w.shape
         self.wp = pack_weight(w)
         self.wtp = pack_weight(w.t().contiguous())
+        self.wd = w.to(torch.bfloat16)        # dense copy for the large-M library GEMM (batched scoring, row f-4)
         self.b = None if b is None else b.float().to(dev).contiguous()
 
 
@@ -50,9 +51,29 @@ def _ws(device, nbytes):
     return _workspace[key]
 
 
-def _linear_raw(x2d, wp, bias, residual, N, K, act, want_pre):
+BIG_M = 192   # rows from which a linear goes to the library GEMM instead of the M <= 128 latency kernel (B >= 4 images)
+
+
+def _linear_raw(x2d, lin, transposed, bias, residual, act, want_pre):
+    """y = x W^T (+ b) (QuickGELU) (+ residual) with bf16 operands and fp32 accumulate / output.  transposed: y = x W (backward)."""
     lib = L.load()
     M = x2d.shape[0]
+    N, K = (lin.K, lin.N) if transposed else (lin.N, lin.K)
+    if M >= BIG_M:
+        # batched scoring (ShapeGen codebook, pose retrieval: hundreds of renders per call): a plain GEMM, where hipBLASLt is the
+        # right tool; the hand-written kernel streams the weights once per 128 rows
+        w = lin.wd if transposed else lin.wd.t()
+        y = torch.mm(x2d.to(torch.bfloat16), w, out_dtype=torch.float32)
+        if bias is not None:
+            y += bias
+        pre = None
+        if act:
+            pre = y.clone() if want_pre else None
+            y = y * torch.sigmoid(1.702 * y)
+        if residual is not None:
+            y += residual
+        return y, pre
+    wp = lin.wtp if transposed else lin.wp
     y = torch.empty(M, N, device=x2d.device, dtype=torch.float32)
     pre = torch.empty_like(y) if (act and want_pre) else None
     ws = _ws(x2d.device, lib.avc_vit_workspace_bytes(min(M, 128), K))
@@ -70,7 +91,7 @@ class LinearFn(torch.autograd.Function):
         shp = x.shape
         x2 = x.reshape(-1, lin.K).contiguous().float()
         r2 = None if residual is None else residual.reshape(-1, lin.N).contiguous().float()
-        y, pre = _linear_raw(x2, lin.wp, lin.b, r2, lin.N, lin.K, act, x.requires_grad or True)
+        y, pre = _linear_raw(x2, lin, False, lin.b, r2, act, True)
         ctx.lin, ctx.act, ctx.has_res = lin, act, residual is not None
         ctx.save_for_backward(pre if pre is not None else y.new_zeros(1))
         return y.reshape(*shp[:-1], lin.N)
@@ -84,7 +105,7 @@ class LinearFn(torch.autograd.Function):
             (pre,) = ctx.saved_tensors
             s = torch.sigmoid(1.702 * pre)
             d2 = d2 * (s + 1.702 * pre * s * (1 - s))
-        dx, _ = _linear_raw(d2.contiguous(), lin.wtp, None, None, lin.K, lin.N, 0, False)
+        dx, _ = _linear_raw(d2.contiguous(), lin, True, None, None, 0, False)
         dres = dy if ctx.has_res else None
         return dx.reshape(*shp[:-1], lin.K), None, None, dres
 

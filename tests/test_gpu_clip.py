@@ -165,3 +165,24 @@ def test_real_openai_weights_when_supplied():
         # a render prompt and an unrelated one must be told apart by the joint embedding the way CLIP does it: cos in (-1, 1), finite
         cs = torch.cosine_similarity(out[0], out[1], dim=0)
         assert torch.isfinite(cs) and cs < 0.99
+
+
+@gpu
+def test_batched_scoring_path_matches_the_per_pair_path():
+    """row f-4 (ShapeGen codebook search / pose retrieval: hundreds of renders per encode_image call): from 512 rows on the linears
+    go to the library GEMM; the embeddings must agree with the M <= 128 kernel path image by image, and with the oracle"""
+    from avatarclip_amd import clip_vit as V
+    sd = C.random_state_dict(0)
+    model = V.ClipVisionB32(sd, torch.device("cuda"))
+    g = torch.Generator().manual_seed(7)
+    img = torch.randn(12, 3, 224, 224, generator=g)          # 12 x 50 = 600 token rows >= BIG_M
+    assert 12 * V.TOKENS >= V.BIG_M
+    big = model.encode_image(img.cuda()).float().cpu()
+    small = torch.cat([model.encode_image(img[i:i + 2].cuda()).float().cpu() for i in range(0, 12, 2)])
+    ref = C.encode_image(sd, img[:4])
+    assert torch.cosine_similarity(big, small, dim=-1).min() > 0.9999
+    assert torch.cosine_similarity(big[:4], ref, dim=-1).min() > 0.9995
+    # gradient to the pixels through the batched path
+    x = img[:12].cuda().requires_grad_(True)
+    model.encode_image(x).square().sum().backward()
+    assert torch.isfinite(x.grad).all() and x.grad.abs().max() > 0

@@ -154,13 +154,18 @@ __device__ __forceinline__ void load8(const float* __restrict__ tab, int s, int 
   out[4] = b[0]; out[5] = b[1]; out[6] = b[2]; out[7] = b[3];
 }
 
+// max(t, 0) as ONE instruction for a value that comes straight out of an MFMA: fmaxf() there makes hipcc emit a second v_max as
+// canonicalisation (the bias add used to provide it for free); v_med3_f32(t, 0, 3e38) needs none.  (NOT inline asm: the hazard
+// recogniser does not look inside an asm, and a VALU read of an MFMA result without the wait states it inserts returns the
+// previous contents of the first result registers -- seen as 12 wrong columns in the last tile of a layer.)
+__device__ __forceinline__ float relu_raw(float t) { return __builtin_amdgcn_fmed3f(t, 0.f, 3.0e38f); }   // (a finite bound: +inf folds back to fmaxnum)
 __device__ __forceinline__ float softplus2(float t) {
   // H = S * Softplus_beta100(t / S)  (nn.Softplus(beta=100), fields.py:68) in base-2 units; raw v_exp_f32 / v_log_f32
 #ifdef AVC_ABL_CHEAPACT   // timing ablation only (what the transcendentals cost)
   return fmaxf(t, 0.f);
 #endif
   const float e = __builtin_amdgcn_exp2f(-fabsf(t));
-  return fmaxf(t, 0.f) + __builtin_amdgcn_logf(1.f + e);
+  return relu_raw(t) + __builtin_amdgcn_logf(1.f + e);
 }
 // sigma(beta a) recovered from H = S * softplus(a):  1 - 2^-H
 __device__ __forceinline__ float sig_from_h(float H) { return 1.f - __builtin_amdgcn_exp2f(-H); }

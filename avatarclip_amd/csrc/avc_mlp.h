@@ -117,9 +117,9 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 #ifndef AVC_PAIR
 #define AVC_PAIR 0   // 1: two output tiles per MFMA stream (independent accumulators), 0: one dependent chain per tile
 #endif
-template <typename V, int KS, int NT, class ST, typename Epi, typename Hook = NoHook>
+template <typename V, int KS, int NT, class ST, typename Epi, typename Hook = NoHook, class Bias = NoBias>
 __device__ __forceinline__ void layer_s(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&in)[KS],
-                                        Epi&& epi, Hook&& hook = NoHook{}) {
+                                        Epi&& epi, Hook&& hook = NoHook{}, const Bias& bias = NoBias{}) {
   constexpr int G = ST::template group<KS>();
   constexpr int NG = (NT + G - 1) / G;
   facc prev0, prev1;
@@ -144,7 +144,7 @@ __device__ __forceinline__ void layer_s(ST& st, const V* __restrict__ blob, int 
         const bool two = AVC_PAIR && (j + 1 < G) && (t + 1 < NT);
         facc a0, a1;
         if (two) tile_mma_pair<V, KS>(st, j, in, a0, a1);
-        else a0 = tile_mma<V, KS>(st, j, in);
+        else a0 = tile_mma<V, KS>(st, j, in, bias, t);
         if (np > 0) {
           epi(tp, prev0);
           if (np > 1) epi(tp + 1, prev1);
@@ -227,9 +227,9 @@ __device__ __forceinline__ void layer_sqd(ST& st, const V* __restrict__ blob, in
                                           Pre&& pre, Epi&& epi, Hook&& hook = NoHook{}) {
   layer_sq_<AVC_DEEP_PF1 != 0, V, KS, NT>(st, blob, offw, after, in, pre, epi, hook);
 }
-template <typename V, int KA, int KB, int NT, class ST, typename Epi, typename Hook = NoHook>
+template <typename V, int KA, int KB, int NT, class ST, typename Epi, typename Hook = NoHook, class Bias = NoBias>
 __device__ __forceinline__ void layer2_s(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&ina)[KA],
-                                         const V (&inb)[KB], Epi&& epi, Hook&& hook = NoHook{}) {
+                                         const V (&inb)[KB], Epi&& epi, Hook&& hook = NoHook{}, const Bias& bias = NoBias{}) {
   constexpr int KS = KA + KB;
   constexpr int G = ST::template group<KS>();
   constexpr int NG = (NT + G - 1) / G;
@@ -251,7 +251,7 @@ __device__ __forceinline__ void layer2_s(ST& st, const V* __restrict__ blob, int
     for (int j = 0; j < G; ++j) {
       const int t = g * G + j;
       if (t < NT) {
-        facc acc = tile_mma2<V, KA, KB>(st, j, ina, inb);
+        facc acc = tile_mma2<V, KA, KB>(st, j, ina, inb, bias, t);
         if (t > 0) { epi(t - 1, prev); interleave_mfma_valu<KS>(); }
         prev = acc;
         __builtin_amdgcn_sched_barrier(0);
@@ -383,40 +383,35 @@ __device__ __forceinline__ float sdf_only(ST& sg, const h8* __restrict__ Wf, TP 
       h8 pef[3];
       pe_to_frags_f16(pe, x, h, pef);
       layer_s<h8, 3, N::HT>(sg, Wf, o.v[OFF_W0], nxt<N, OFF_WM0>(sg, Wf, o), pef, AVC_EPI(
-        float b[16], a[16];
-        load16(T + o.v[OFF_B0], t, h, b);
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);
+        float a[16];
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r]);
         acc_to_frags(a, h1[2 * t], h1[2 * t + 1]);
-      ));
+      ), NoHook{}, TabBias{T + o.v[OFF_B0], h});
     }
     if constexpr (N::NMID == 2) {
       h8 hm0[N::HK];
       layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wf, o), h1, AVC_EPI(
-        float b[16], a[16];
-        load16(T + o.v[OFF_BM0], t, h, b);
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);
+        float a[16];
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r]);
         acc_to_frags(a, hm0[2 * t], hm0[2 * t + 1]);
-      ));
+      ), NoHook{}, TabBias{T + o.v[OFF_BM0], h});
       layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wf, o), hm0, AVC_EPI(
-        float b[16], a[16];
-        load16(T + o.v[OFF_BM1], t, h, b);
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);
+        float a[16];
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r]);
         acc_to_frags(a, hlast[2 * t], hlast[2 * t + 1]);
-      ));
+      ), NoHook{}, TabBias{T + o.v[OFF_BM1], h});
     } else {
       layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wf, o), h1, AVC_EPI(
-        float b[16], a[16];
-        load16(T + o.v[OFF_BM0], t, h, b);
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);
+        float a[16];
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r]);
         acc_to_frags(a, hlast[2 * t], hlast[2 * t + 1]);
-      ));
+      ), NoHook{}, TabBias{T + o.v[OFF_BM0], h});
     }
   }
   layer_s<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], no_next(), hlast, AVC_EPI(
-    float b[16], w[16];
-    load16(T + o.v[OFF_BS], t, h, b);
+    float w[16];
     load16(T + o.v[OFF_WL0_ACC], t, h, w);
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) part += w[r] * softplus2(acc[r] + b[r]);
-  ));
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) part += w[r] * softplus2(acc[r]);
+  ), NoHook{}, TabBias{T + o.v[OFF_BS], h});
   return xhalf_sum(part) + T[o.v[OFF_BL0]];
 }

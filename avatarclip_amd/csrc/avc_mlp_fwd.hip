@@ -140,13 +140,15 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
       h8 pef[3];
       pe_to_frags_f16(pe, x, h, pef);
       // every tile store below is issued by the hook of the NEXT layer (right after its first group barrier, see avc_mlp.h)
-#define AVC_F_ACT(OFFB, OUT)                                                                  \
-  AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
-          _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);  \
+      // (the bias rows enter through the accumulators: TabBias, avc_stage.h)
+#define AVC_F_BIAS(OFFB) TabBias{T + o.v[OFFB], h}
+#define AVC_F_ACT(OUT)                                                                        \
+  AVC_EPI(float a[16];                                                                        \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r]);           \
           acc_to_frags(a, OUT[2 * t], OUT[2 * t + 1]);)
-#define AVC_F_LAST(OFFB)                                                                      \
-  AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
-          _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r] + b[r]);  \
+#define AVC_F_LAST()                                                                          \
+  AVC_EPI(float b[16], a[16];                                                                 \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r]);           \
           load16(T + o.v[OFF_WL0_ACC], t, h, b);                                              \
           _Pragma("unroll") for (int r = 0; r < 16; ++r) part += b[r] * a[r];                 \
           acc_to_frags(a, hs[2 * t], hs[2 * t + 1]);                                          \
@@ -158,35 +160,34 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
           pin2(g_s[2 * t], g_s[2 * t + 1]);)
       {
         h8 h1[N::HK];
-        layer_s<h8, 3, N::HT>(sg, Wf, o.v[OFF_W0], nxt<N, OFF_WM0>(sg, Wf, o), pef, AVC_F_ACT(OFF_B0, h1), AVC_HOOK(
+        layer_s<h8, 3, N::HT>(sg, Wf, o.v[OFF_W0], nxt<N, OFF_WM0>(sg, Wf, o), pef, AVC_F_ACT(h1), AVC_HOOK(
           if constexpr (TRAIN) {
             h8 zf;
             _Pragma("unroll") for (int j = 0; j < 8; ++j) zf[j] = (_Float16)0.f;
             tile_store<false>(tiles, L::P_H0, pef[0], pef[1]);
             tile_store<false>(tiles, L::P_H0 + 1, pef[2], zf);
-          }));
+          }), AVC_F_BIAS(OFF_B0));
         h8 hm0[N::HK];
         if constexpr (N::NMID == 2) {
-          layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wf, o), h1, AVC_F_ACT(OFF_BM0, hm0),
-                                    AVC_HOOK(tiles_store<true, N::HT>(tiles, L::P_H1, h1);));
+          layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wf, o), h1, AVC_F_ACT(hm0),
+                                    AVC_HOOK(tiles_store<true, N::HT>(tiles, L::P_H1, h1);), AVC_F_BIAS(OFF_BM0));
           h8 hm1[N::HK];
-          layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wf, o), hm0, AVC_F_ACT(OFF_BM1, hm1),
-                                    AVC_HOOK(tiles_store<true, N::HT>(tiles, L::P_HM, hm0);));
-          layer_s<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], nxt<N, OFF_WL>(sg, Wf, o), hm1, AVC_F_LAST(OFF_BS),
-                                    AVC_HOOK(tiles_store<true, N::HT>(tiles, L::P_HM + N::HT, hm1);));
+          layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wf, o), hm0, AVC_F_ACT(hm1),
+                                    AVC_HOOK(tiles_store<true, N::HT>(tiles, L::P_HM, hm0);), AVC_F_BIAS(OFF_BM1));
+          layer_s<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], nxt<N, OFF_WL>(sg, Wf, o), hm1, AVC_F_LAST(),
+                                    AVC_HOOK(tiles_store<true, N::HT>(tiles, L::P_HM + N::HT, hm1);), AVC_F_BIAS(OFF_BS));
         } else {
-          layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wf, o), h1, AVC_F_ACT(OFF_BM0, hm0),
-                                    AVC_HOOK(tiles_store<true, N::HT>(tiles, L::P_H1, h1);));
-          layer_s<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], nxt<N, OFF_WL>(sg, Wf, o), hm0, AVC_F_LAST(OFF_BS),
-                                    AVC_HOOK(tiles_store<true, N::HT>(tiles, L::P_HM, hm0);));
+          layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wf, o), h1, AVC_F_ACT(hm0),
+                                    AVC_HOOK(tiles_store<true, N::HT>(tiles, L::P_H1, h1);), AVC_F_BIAS(OFF_BM0));
+          layer_s<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], nxt<N, OFF_WL>(sg, Wf, o), hm0, AVC_F_LAST(),
+                                    AVC_HOOK(tiles_store<true, N::HT>(tiles, L::P_HM, hm0);), AVC_F_BIAS(OFF_BS));
         }
       }
       sdf = xhalf_sum(part) + T[o.v[OFF_BL0]];
       // feature = rows 1..H of the last layer on u = [h_s ; pe]/sqrt2 (1/sqrt2 folded into the packed weights)
       layer2_s<h8, N::SK, 3, N::HT>(sg, Wf, o.v[OFF_WL], nxt<N, OFF_WST>(sg, Wf, o), hs, pef, AVC_EPI(
-        float b[16], a[16];
-        load16(T + o.v[OFF_BL], t, h, b);
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = acc[r] + b[r];
+        float a[16];
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = acc[r];
         h8 f0, f1;
         acc_to_frags(a, f0, f1);
         tile_store<true>(tiles, L::P_FEAT + t, f0, f1);
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
         if constexpr (TRAIN && !ABL_NOMISC) {
           tiles_store<false, N::ST>(tiles, L::P_HS, hs);
           tiles_store<false, N::ST>(tiles, L::P_GAS, g_s);
-        }));
+        }), AVC_F_BIAS(OFF_BL));
     }
     // ---------------------------------------------------------------- normal sweep: g_h(prev) = W^T g_a ; g_a(prev) = g_h sigma(h_prev)
     float n[3];
@@ -255,11 +256,11 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
       }
       // ReLU layers; TRAIN: the activations go out as weight-gradient operands and their sign bits (16 per tile and lane) as the
       // masks of the backward pass -- both from the hook of the next layer
-#define AVC_F_RELU(OFFB, OUT, ML)                                                             \
-  AVC_EPI(float b[16], a[16]; load16(T + o.v[OFFB], t, h, b);                                \
+#define AVC_F_RELU(OUT, ML)                                                                   \
+  AVC_EPI(float a[16];                                                                        \
           unsigned bits = 0u;                                                                 \
           _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                    \
-            a[r] = fmaxf(acc[r] + b[r], 0.f); if (TRAIN) bits |= (a[r] > 0.f ? 1u : 0u) << r; } \
+            a[r] = relu_raw(acc[r]); if (TRAIN) bits |= (a[r] > 0.f ? 1u : 0u) << r; }        \
           if constexpr (TRAIN && !ABL_NOMASK) mk[((ML) * N::HT + t) * 64] = (unsigned short)bits; \
           acc_to_frags(a, OUT[2 * t], OUT[2 * t + 1]);)
 #define AVC_F_RSTORE(PT, R)                                                                   \
@@ -267,21 +268,21 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
       h8 r1[N::HK];
       h8 r2[N::HK];
       if constexpr (N::NCMID == 1) {
-        layer2_s<h8, N::HK, 1, N::HT>(sg, Wf, o.v[OFF_C0], nxt<N, OFF_CM0>(sg, Wf, o), feat, xn, AVC_F_RELU(OFF_CB0, r1, 0), AVC_HOOK(
+        layer2_s<h8, N::HK, 1, N::HT>(sg, Wf, o.v[OFF_C0], nxt<N, OFF_CM0>(sg, Wf, o), feat, xn, AVC_F_RELU(r1, 0), AVC_HOOK(
           if constexpr (TRAIN) {
             h8 zf;
             _Pragma("unroll") for (int j = 0; j < 8; ++j) zf[j] = (_Float16)0.f;
             tile_store<false>(tiles, L::P_XN, xn[0], zf);
-          }));
-        layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_CM0], nxt<N, OFF_CH>(sg, Wf, o), r1, AVC_F_RELU(OFF_CBM0, r2, 1),
-                                  AVC_F_RSTORE(L::P_R1, r1));
+          }), AVC_F_BIAS(OFF_CB0));
+        layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_CM0], nxt<N, OFF_CH>(sg, Wf, o), r1, AVC_F_RELU(r2, 1),
+                                  AVC_F_RSTORE(L::P_R1, r1), AVC_F_BIAS(OFF_CBM0));
       } else {
-        layer2_s<h8, N::HK, 1, N::HT>(sg, Wf, o.v[OFF_C0], nxt<N, OFF_CH>(sg, Wf, o), feat, xn, AVC_F_RELU(OFF_CB0, r1, 0), AVC_HOOK(
+        layer2_s<h8, N::HK, 1, N::HT>(sg, Wf, o.v[OFF_C0], nxt<N, OFF_CH>(sg, Wf, o), feat, xn, AVC_F_RELU(r1, 0), AVC_HOOK(
           if constexpr (TRAIN) {
             h8 zf;
             _Pragma("unroll") for (int j = 0; j < 8; ++j) zf[j] = (_Float16)0.f;
             tile_store<false>(tiles, L::P_XN, xn[0], zf);
-          }));
+          }), AVC_F_BIAS(OFF_CB0));
 #pragma unroll
         for (int s = 0; s < N::HK; ++s) r2[s] = r1[s];
       }

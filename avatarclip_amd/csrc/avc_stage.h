@@ -141,21 +141,40 @@ __device__ __forceinline__ void tile_mma_pair(const ST& st, int j, const V (&in)
   }
 }
 
+// Where the accumulator of an output tile starts: zero, or the tile's bias row read from the fp32 table in LDS straight into
+// the accumulator registers (the C operand of the first MFMA) -- one VALU add per output element less in the epilogue, on an
+// engine whose VALU time adds to its MFMA time.
+struct NoBias { static constexpr bool on = false; };
+struct TabBias { static constexpr bool on = true; lds_tab_t tab; int h; };
 // MFMAs of tile j of the current group (KS k-steps per tile) against the register-resident B operands
-template <typename V, int KS, class ST>
-__device__ __forceinline__ facc tile_mma(const ST& st, int j, const V (&in)[KS]) {
+template <typename V, int KS, class ST, class B = NoBias>
+__device__ __forceinline__ facc tile_mma(const ST& st, int j, const V (&in)[KS], const B& bias = NoBias{}, int t = 0) {
   const V* a = reinterpret_cast<const V*>(st.lds + st.par * ST::BUF_BYTES + j * KS * 1024) + st.lane;
   facc acc;
+  if constexpr (B::on) {
+    float b[16];
+    load16(bias.tab, t, bias.h, b);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[r] = b[r];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  }
   return mma_chain_lds<V, KS>(a, in, acc);
 }
-template <typename V, int KA, int KB, class ST>
-__device__ __forceinline__ facc tile_mma2(const ST& st, int j, const V (&ina)[KA], const V (&inb)[KB]) {
+template <typename V, int KA, int KB, class ST, class B = NoBias>
+__device__ __forceinline__ facc tile_mma2(const ST& st, int j, const V (&ina)[KA], const V (&inb)[KB], const B& bias = NoBias{}, int t = 0) {
   const V* a = reinterpret_cast<const V*>(st.lds + st.par * ST::BUF_BYTES + j * (KA + KB) * 1024) + st.lane;
   facc acc;
+  if constexpr (B::on) {
+    float b[16];
+    load16(bias.tab, t, bias.h, b);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[r] = b[r];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  }
   acc = mma_chain_lds<V, KA>(a, ina, acc);
   return mma_chain_lds<V, KB>(a + KA * 64, inb, acc);
 }

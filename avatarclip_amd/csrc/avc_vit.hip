@@ -33,13 +33,16 @@ __global__ __launch_bounds__(64) void vit_pack_x_kernel(const float* __restrict_
 
 // One workgroup per 32 output columns; the K range is dealt round-robin to 8 wavefronts (k-step s goes to wave s % 8), each
 // wave keeps 6 k-steps of loads in flight (the GEMM is a latency chain otherwise: M <= 128 rows give the matrix core nothing
-// to hide a round trip behind), partial sums are reduced through LDS in a fixed tree (deterministic).
+// to hide a round trip behind).  Every wave parks its partial tiles in LDS ([wave][m-tile][row][lane]: conflict-free both
+// ways), ONE barrier, then the 16 MT accumulator rows are dealt to the 8 waves: each sums the 8 partials of its rows in a fixed
+// order (deterministic) and runs the epilogue (bias, QuickGELU, residual, store) for them -- a tree reduction with the whole
+// epilogue on wave 0 cost three barrier pairs and 64 serial load / store pairs on one wave.
 template <int MT>
 __global__ __launch_bounds__(64 * VIT_WAVES) void vit_linear_kernel(const b8* __restrict__ Xs, const b8* __restrict__ Wp,
                                                                     const float* __restrict__ bias, const float* __restrict__ res,
                                                                     float* __restrict__ Y, float* __restrict__ Ypre, int M, int N,
                                                                     int K, int act) {
-  __shared__ float red[VIT_WAVES / 2][MT][64][16];
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [VIT_WAVES][MT][16][64]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int n = lane & 31, h = lane >> 5;
   const int t = blockIdx.x;           // output column tile
@@ -57,43 +60,30 @@ __global__ __launch_bounds__(64 * VIT_WAVES) void vit_linear_kernel(const b8* __
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = MF<b8>::mma(xp[((long)m * KS + s) * 64], w, acc[m]);
   }
-  // tree reduction 8 -> 4 -> 2 -> 1
 #pragma unroll
-  for (int half = VIT_WAVES / 2; half >= 1; half >>= 1) {
-    if (wv >= half && wv < 2 * half) {
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+    for (int r = 0; r < 16; ++r) red[((wv * MT + m) * 16 + r) * 64 + lane] = acc[m][r];
+  __syncthreads();
+  const int col = 32 * t + n;
+  const float bv = bias ? bias[col] : 0.f;
+  constexpr int PER_WAVE = MT * 16 / VIT_WAVES;   // accumulator rows per wave: 2 MT
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[wv - half][m][lane][r] = acc[m][r];
-    }
-    __syncthreads();
-    if (wv < half) {
+  for (int q = 0; q < PER_WAVE; ++q) {
+    const int item = wv * PER_WAVE + q, m = item >> 4, r = item & 15;
+    const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
+    float v = 0.f;
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] += red[wv][m][lane][r];
-    }
-    __syncthreads();
-  }
-  if (wv == 0) {
-    const int col = 32 * t + n;
-    const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < M) {
-          float v = acc[m][r] + bv;
-          const long o = (long)row * N + col;
-          if (act == 1) {
-            if (Ypre) Ypre[o] = v;
-            v = v * sigmoidf_(1.702f * v);
-          }
-          if (res) v += res[o];
-          Y[o] = v;
-        }
+    for (int w = 0; w < VIT_WAVES; ++w) v += red[((w * MT + m) * 16 + r) * 64 + lane];
+    if (row < M) {
+      v += bv;
+      const long o = (long)row * N + col;
+      if (act == 1) {
+        if (Ypre) Ypre[o] = v;
+        v = v * sigmoidf_(1.702f * v);
       }
+      if (res) v += res[o];
+      Y[o] = v;
     }
   }
 }
@@ -117,11 +107,18 @@ extern "C" int avc_vit_linear(const float* x, const void* w_packed, const float*
   hipLaunchKernelGGL(vit_pack_x_kernel, dim3(K / 16, mt), dim3(64), 0, s, x, xs, M, K);
   const dim3 grid(N / 32), block(64 * VIT_WAVES);
   const b8* wp = (const b8*)w_packed;
+  const int lds = VIT_WAVES * mt * 4096;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)vit_linear_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, VIT_WAVES * 3 * 4096);
+    (void)hipFuncSetAttribute((const void*)vit_linear_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, VIT_WAVES * 4 * 4096);
+    attr_set = true;
+  }
   switch (mt) {
-    case 1: hipLaunchKernelGGL((vit_linear_kernel<1>), grid, block, 0, s, xs, wp, bias, residual, y, y_pre, M, N, K, act); break;
-    case 2: hipLaunchKernelGGL((vit_linear_kernel<2>), grid, block, 0, s, xs, wp, bias, residual, y, y_pre, M, N, K, act); break;
-    case 3: hipLaunchKernelGGL((vit_linear_kernel<3>), grid, block, 0, s, xs, wp, bias, residual, y, y_pre, M, N, K, act); break;
-    default: hipLaunchKernelGGL((vit_linear_kernel<4>), grid, block, 0, s, xs, wp, bias, residual, y, y_pre, M, N, K, act); break;
+    case 1: hipLaunchKernelGGL((vit_linear_kernel<1>), grid, block, lds, s, xs, wp, bias, residual, y, y_pre, M, N, K, act); break;
+    case 2: hipLaunchKernelGGL((vit_linear_kernel<2>), grid, block, lds, s, xs, wp, bias, residual, y, y_pre, M, N, K, act); break;
+    case 3: hipLaunchKernelGGL((vit_linear_kernel<3>), grid, block, lds, s, xs, wp, bias, residual, y, y_pre, M, N, K, act); break;
+    default: hipLaunchKernelGGL((vit_linear_kernel<4>), grid, block, lds, s, xs, wp, bias, residual, y, y_pre, M, N, K, act); break;
   }
   return avc_check_launch("avc_vit_linear");
 }

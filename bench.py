@@ -158,7 +158,9 @@ def cpu_baseline(spp, rays=4096, iters=2, max_threads=16):
     t = float(np.mean(times[1:])) if len(times) > 1 else float(times[0])
     return {"value": R / t, "unit": "rays/s", "cores": nthreads, "host_cores": os.cpu_count(), "kind": "port",
             "sample": "%d rays (%dx%d view) x %d spp, full nets, full step incl. 2 CLIP passes + Adam, %d timed iters, %.2f s/iter"
-                      % (R, side, side, spp, max(len(times) - 1, 1), t)}
+                      % (R, side, side, spp, max(len(times) - 1, 1), t),
+            # the reference's OWN modules beside this port, at 64^2 and 224^2 rays (needs /root/reference: build container only)
+            "reference_vs_port_table": "profiles/r02_cpu_reference_vs_port.md"}
 
 
 def main():

@@ -27,3 +27,29 @@ def test_two_ranks_on_the_hip_path_equal_single_gpu_accumulation():
     gn = torch.cat([g.reshape(-1) for g in mean_grads]).norm()
     for g1, g2 in zip(mean_grads, a["grads"]):
         assert (g1 - g2).norm() <= 1e-4 * (g1.norm() + 1e-3 * gn)
+
+
+@gpu
+def test_bench_spawns_its_own_ranks_and_reports_the_whole_job():
+    """`python bench.py --gpus 2` with no WORLD_SIZE starts the two ranks itself (the driver's contract); both ranks share device 0
+    here (AVC_SINGLE_DEVICE + gloo, the development path for a 1-GPU box).  The JSON line must say n_gpus = 2 and count the rays of
+    BOTH ranks; without AVC_SINGLE_DEVICE the same command must refuse to run on a box with one device."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AVC_SINGLE_DEVICE="1", AVC_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--res", "64", "--small", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 1
+    assert abs(out["value"] - 2 * 64 * 64 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+    if torch.cuda.device_count() < 2:
+        env2 = dict(os.environ); env2.pop("AVC_SINGLE_DEVICE", None); env2.pop("WORLD_SIZE", None); env2.pop("RANK", None)
+        r2 = subprocess.run(cmd, env=env2, capture_output=True, text=True, timeout=120, cwd=root)
+        assert r2.returncode != 0 and "device" in (r2.stderr + r2.stdout)

@@ -21,7 +21,7 @@
 // HBM-bound by construction: 2 KiB per tile per block is read exactly once per pair it takes part in.
 // ---------------------------------------------------------------------------------------------
 #define WG_TB_MAX 9
-#define WG_TILES_MAX 17
+#define WG_TILES_MAX 18
 #define WG_BUF_BYTES (WG_TILES_MAX * 2048)
 #ifndef WG_DEPTH
 #define WG_DEPTH 4   // blocks in the LDS ring: one being contracted, WG_DEPTH - 1 copies in flight
@@ -186,6 +186,150 @@ __device__ __forceinline__ void weight_grad_body(char* lds, const b8* __restrict
   }
 }
 
+// The merged last-layer product: A = [ybar[1:] (8 tiles) | d_sdf row (1 tile)], B = [hs (7) | pe (2)], 9 x 9 output tiles, so that
+// [hs | pe] is read from HBM once for the 256 feature rows AND the sdf row.  Waves 4 x 2 over the 8 x 9 part as in the generic
+// body (A tiles wa, wa + 4; B tiles wb, wb + 2, ..: 10 products for wb = 0, 8 for wb = 1); the nine products of the ninth A tile go to
+// the waves that have the matching B tile in registers anyway: wave (wa, 1) takes B tile 2 wa + 1 and -- one more LDS read -- 2 wa,
+// wave (0, 0) takes B tile 8: 12 accumulators at most.  B fragments are streamed one tile ahead of their MFMAs (all five at once,
+// as in the generic body, do not fit beside 12 accumulators).
+__device__ __forceinline__ void weight_grad_body_9x9(char* lds, const b8* __restrict__ panels, int ptiles, int pa, int pb, int type_a,
+                                                     int type_b, long nblk, float* __restrict__ partial,
+                                                     float* __restrict__ bias_partial, int out_elems, int bias_elems) {
+  constexpr int TA = 9, TB = 9, NT = TA + TB;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wa = wv & 3, wb = wv >> 2;
+  const int split = blockIdx.x, nsplit = gridDim.x;
+  const long b0 = nblk * split / nsplit, b1 = nblk * (split + 1) / nsplit;
+  constexpr int nchunk = NT * 2;
+  const int my_chunks = (nchunk - wv + 7) >> 3;
+  const int src_lo = ((lane >> 2) & 3) * 32 + 4 * (lane >> 4) + (lane & 3);
+  auto issue = [&](long blk, int slot) {
+    const char* base = reinterpret_cast<const char*>(panels + blk * (long)ptiles * 128);
+    for (int c = wv; c < nchunk; c += 8) {
+      const int tix = c >> 1;
+      const int tile = tix < TA ? pa + tix : pb + (tix - TA);
+      const char* g = base + ((long)tile * 128 + src_lo + (c & 1) * 16) * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(lds + slot * WG_BUF_BYTES + c * 1024), 16, 0, 0);
+    }
+  };
+  const int lane_off = (((lane >> 5) * 2) * 16 + (((lane >> 4) & 1) * 2 + (lane & 1)) * 4 + ((lane & 15) >> 2)) * 16 + 8 * ((lane & 3) >> 1);
+  facc acc[10], ex[2];
+#pragma unroll
+  for (int q = 0; q < 10; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ex[q][r] = 0.f;
+  float bsum[2] = {0.f, 0.f}, xsum = 0.f;
+  const bool has_x = wb == 1 || wa == 0;          // waves that hold products of the ninth A tile
+  const int xk = wb == 1 ? wa : 4;                 // the regular B slot k whose tile also meets the ninth A tile
+  for (int d = 0; d < WG_DEPTH - 1; ++d)
+    if (b0 + d < b1) issue(b0 + d, d);
+  int slot = 0;
+  for (long blk = b0; blk < b1; ++blk) {
+    long younger = b1 - 1 - blk;
+    if (younger > WG_DEPTH - 2) younger = WG_DEPTH - 2;
+    wait_vmcnt((int)younger * my_chunks);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (blk + WG_DEPTH - 1 < b1) issue(blk + WG_DEPTH - 1, (slot + WG_DEPTH - 1) % WG_DEPTH);
+    lds_char* buf = (lds_char*)(lds + slot * WG_BUF_BYTES) + lane_off;
+    auto load_b = [&](int tb, b8& f0, b8& f1) {
+      f0 = tr_frag(buf + (TA + tb) * 2048, 0);
+      f1 = tr_frag(buf + (TA + tb) * 2048, 1);
+    };
+    b8 a[2][2], sa[2], c0, c1, n0, n1;
+    load_b(wb, c0, c1);
+    n0 = c0; n1 = c1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      a[i][0] = tr_frag(buf + (wa + 4 * i) * 2048, 0);
+      a[i][1] = tr_frag(buf + (wa + 4 * i) * 2048, 1);
+    }
+    if (has_x) { sa[0] = tr_frag(buf + 8 * 2048, 0); sa[1] = tr_frag(buf + 8 * 2048, 1); }
+    if (type_a == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { a[i][0] = f16_to_bf16(a[i][0]); a[i][1] = f16_to_bf16(a[i][1]); }
+      if (has_x) { sa[0] = f16_to_bf16(sa[0]); sa[1] = f16_to_bf16(sa[1]); }
+    }
+    if (bias_partial && wb == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum[i] += (float)a[i][0][j] + (float)a[i][1][j];
+    }
+    if (bias_partial && wv == 4) {   // wave (0, 1): row sums of the ninth A tile
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xsum += (float)sa[0][j] + (float)sa[1][j];
+    }
+    // regular slots k = 0..4 (B tile wb + 2 k), then -- waves with wb = 1 -- the extra B tile 2 wa; each tile is requested before
+    // the MFMAs of the previous one
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int tb_next = (k + 1 < 5) ? wb + 2 * (k + 1) : 2 * wa;
+      const bool next_ok = (k + 1 < 5) ? (tb_next < TB) : (k + 1 == 5 && wb == 1);
+      if (next_ok) load_b(tb_next, n0, n1);
+      asm volatile("" : "+v"(n0), "+v"(n1));
+      const bool cur_ok = (k < 5) ? (wb + 2 * k < TB) : (wb == 1);
+      if (cur_ok) {
+        if (type_b == 0) { c0 = f16_to_bf16(c0); c1 = f16_to_bf16(c1); }
+        if (k < 5) {
+          acc[k] = MF<b8>::mma(a[0][0], c0, acc[k]);
+          acc[k] = MF<b8>::mma(a[0][1], c1, acc[k]);
+          acc[5 + k] = MF<b8>::mma(a[1][0], c0, acc[5 + k]);
+          acc[5 + k] = MF<b8>::mma(a[1][1], c1, acc[5 + k]);
+          if (has_x && k == xk) {
+            ex[0] = MF<b8>::mma(sa[0], c0, ex[0]);
+            ex[0] = MF<b8>::mma(sa[1], c1, ex[0]);
+          }
+        } else {
+          ex[1] = MF<b8>::mma(sa[0], c0, ex[1]);
+          ex[1] = MF<b8>::mma(sa[1], c1, ex[1]);
+        }
+      }
+      c0 = n0; c1 = n1;
+    }
+    slot = (slot + 1) % WG_DEPTH;
+  }
+  float* dst = partial + (long)split * out_elems;
+  auto store_tile = [&](int ta, int tb, const facc& v16) {
+    f4* d4 = reinterpret_cast<f4*>(dst + ((long)(ta * TB + tb) * 64 + lane) * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f4 v;
+      v[0] = v16[4 * q]; v[1] = v16[4 * q + 1]; v[2] = v16[4 * q + 2]; v[3] = v16[4 * q + 3];
+      d4[q] = v;
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    if (wb + 2 * k < TB) {
+      store_tile(wa, wb + 2 * k, acc[k]);
+      store_tile(wa + 4, wb + 2 * k, acc[5 + k]);
+    }
+  }
+  if (has_x) store_tile(8, wb + 2 * xk, ex[0]);
+  if (wb == 1) store_tile(8, 2 * wa, ex[1]);
+  if (bias_partial) {
+    if (wb == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float sx = xhalf_sum(bsum[i]);
+        if (lane < 32) bias_partial[(long)split * bias_elems + (wa + 4 * i) * 32 + lane] = sx;
+      }
+    }
+    if (wv == 4) {
+      const float sx = xhalf_sum(xsum);
+      if (lane < 32) bias_partial[(long)split * bias_elems + 8 * 32 + lane] = sx;
+    }
+  }
+}
+
 // every product of one backward pass in ONE launch: blockIdx.y = pair, blockIdx.x = K-split.  Workgroups are dispatched
 // x-fastest, so the tail of one pair's splits overlaps the head of the next pair's instead of draining the chip 17 times.
 #define WG_MAX_PAIRS 24
@@ -202,6 +346,8 @@ __global__ __launch_bounds__(512) void weight_grad_all_kernel(const b8* __restri
   if (d[1] > 1 && d[3] > 2 && d[3] <= 8) {
     if (d[7] == 0) weight_grad_body<4, 2>(WG_ARGS, 2);
     else weight_grad_body<2, 4>(WG_ARGS, 4);
+  } else if (d[1] == 9 && d[3] == 9) {
+    weight_grad_body_9x9(lds, panels, ptiles, d[0], d[2], d[6], d[7], nblk, partial + d[4], bp, out_elems, bias_elems);
   } else if (d[1] > 1 && d[3] > 8) {
     weight_grad_body<2, 5>(WG_ARGS, 4);
   } else if (d[1] > 1) {
@@ -219,8 +365,9 @@ extern "C" int avc_weight_grad_all(const void* panels, int ptiles, int npairs, c
   WgPairs pp;
   for (int i = 0; i < npairs; ++i) {
     for (int k = 0; k < 8; ++k) pp.v[i][k] = pairs[i * 8 + k];
-    if (pp.v[i][1] < 1 || pp.v[i][1] > 8 || pp.v[i][3] < 1 || pp.v[i][3] > WG_TB_MAX) {
-      avc_set_error("avc_weight_grad_all: 1 <= ta <= 8, 1 <= tb <= 9");
+    const bool merged = pp.v[i][1] == 9 && pp.v[i][3] == 9;
+    if (!merged && (pp.v[i][1] < 1 || pp.v[i][1] > 8 || pp.v[i][3] < 1 || pp.v[i][3] > WG_TB_MAX)) {
+      avc_set_error("avc_weight_grad_all: 1 <= ta <= 8, 1 <= tb <= 9 (or the 9 x 9 product)");
       return 1;
     }
   }

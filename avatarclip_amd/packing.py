@@ -418,8 +418,10 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
         a, b = feat_std(SKIP), feat_pe(lo_as_x, shift=SKIP)
         return lambda f: a(f) if f < 32 * ST else b(f - 32 * ST)
     hs_scale = lambda t_b: 1 / (SQ2 * S_B2) if t_b < ST else 1 / SQ2
-    add_pair(P["DFEAT"], HT, P["HS"], ST + 2, ll, r1, last_cols(True), scale=hs_scale, bname=bl)
-    add_pair(P["SDF"], 1, P["HS"], ST + 2, ll, r0, last_cols(True), scale=hs_scale, bname=bl)
+    # rows 1..H (DFEAT tiles) and row 0 (the SDF tile right behind them) in ONE product: [hs | pe] is read once for both
+    assert P["SDF"] == P["DFEAT"] + HT
+    rows_last = lambda f: r1(f) if f < 32 * HT else r0(f - 32 * HT)
+    add_pair(P["DFEAT"], HT + 1, P["HS"], ST + 2, ll, rows_last, last_cols(True), scale=hs_scale, bname=bl)
     add_pair(P["ONE"], 1, P["GBHS"], ST + 2, ll, r0, last_cols(False), scale=1 / SQ2)
     # colour
     fx = feat_xn()

@@ -43,7 +43,7 @@ KERNEL_ROOFLINES = {
                                        "(70 tiles) are on top of the algorithmic bytes"),
     "avc_weight_grad(all pairs)": dict(kernel="weight_grad_all_kernel", bound="hbm", flop_per_point=F_PT, bytes_per_point=180 * TILE,
                                        note="dW = sum_points A^T B from the operand panels (F_pt FLOP/point, AI = 103 FLOP/B < ridge 312): "
-                                            "HBM-bound by construction; 193 tile reads per block for 180 distinct tiles"),
+                                            "HBM-bound by construction; 184 tile reads per block for 180 distinct tiles"),
 }
 
 

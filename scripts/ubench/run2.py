@@ -57,3 +57,6 @@ if "copy" in sys.argv:
     for nt in (0, 1):
         ms = timed(lambda: lib.ub2_copy(src.data_ptr(), dst.data_ptr(), ntiles, nt, 2048, st))
         print("copy of %d tiles x 2 KiB (nt=%d): %.3f ms, %.0f GB/s read + the same written" % (ntiles, nt, ms, ntiles * 2048 / ms / 1e6), flush=True)
+    for nt, what in ((2, "write only"), (3, "read only")):
+        ms = timed(lambda: lib.ub2_copy(src.data_ptr(), dst.data_ptr(), ntiles, nt, 2048, st))
+        print("%s, %d tiles x 2 KiB: %.3f ms, %.0f GB/s" % (what, ntiles, ms, ntiles * 2048 / ms / 1e6), flush=True)

@@ -99,6 +99,16 @@ __global__ __launch_bounds__(512) void ub2_copy_kernel(const v4i* __restrict__ s
     const v4i* s = src + t * 128 + lane;
     v4i* d = dst + t * 128 + lane;
     v4i a, b;
+    if (nt == 2) {            // write only
+      a.x = (int)t; a.y = lane; a.z = 0; a.w = 1; b = a;
+      __builtin_nontemporal_store(a, d); __builtin_nontemporal_store(b, d + 64);
+      continue;
+    }
+    if (nt == 3) {            // read only (the sum keeps the loads alive; one lane in a million writes)
+      a = __builtin_nontemporal_load(s); b = __builtin_nontemporal_load(s + 64);
+      if ((a.x ^ b.y) == 0x7fffffff) d[0] = a;
+      continue;
+    }
     if (nt) { a = __builtin_nontemporal_load(s); b = __builtin_nontemporal_load(s + 64); }
     else { a = s[0]; b = s[64]; }
     a.x += 1; b.y += 1;

@@ -53,3 +53,17 @@ def test_bench_spawns_its_own_ranks_and_reports_the_whole_job():
         env2 = dict(os.environ); env2.pop("AVC_SINGLE_DEVICE", None); env2.pop("WORLD_SIZE", None); env2.pop("RANK", None)
         r2 = subprocess.run(cmd, env=env2, capture_output=True, text=True, timeout=120, cwd=root)
         assert r2.returncode != 0 and "device" in (r2.stderr + r2.stdout)
+
+
+@gpu
+def test_pinned_upload_ring_survives_wraparound():
+    """h2d.upload: more uploads than the ring has rows, values checked AFTER all of them were enqueued (a row must not be reused
+    before its copy has completed)"""
+    import numpy as np
+    import torch
+    from avatarclip_amd import h2d
+    outs = [h2d.upload(np.full((4, 4), float(i)), "cuda") for i in range(300)]
+    torch.cuda.synchronize()
+    assert all(float(o[1, 2]) == float(i) and o.shape == (4, 4) for i, o in enumerate(outs))
+    big = h2d.upload(np.arange(1000.0), "cuda")          # larger than a ring row: plain path
+    assert float(big[999]) == 999.0

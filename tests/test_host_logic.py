@@ -172,3 +172,16 @@ def test_conf_parser_reads_every_reference_conf():
         assert list(sk) == [c.get_int("model.sdf_network.n_layers")]
         if "clip" in c:
             assert isinstance(c.get_string("clip.prompt"), str) and len(c.get_string("clip.prompt")) > 3
+
+
+def test_h2d_helpers_on_cpu_and_constant_cache():
+    """avatarclip_amd/h2d.py: on a CPU device `upload` is a plain conversion, `const` returns ONE cached tensor per (values, device, dtype)"""
+    import numpy as np
+    import torch
+    from avatarclip_amd import h2d
+    a = h2d.upload(np.arange(12.0).reshape(3, 4), "cpu")
+    assert a.dtype == torch.float32 and a.shape == (3, 4) and float(a[2, 3]) == 11.0
+    c1 = h2d.const((0.5, 0.25, 0.125), "cpu")
+    c2 = h2d.const([0.5, 0.25, 0.125], "cpu")
+    assert c1 is c2 and c1.tolist() == [0.5, 0.25, 0.125]
+    assert h2d.const((0.5, 0.25, 0.125), "cpu", torch.float64) is not c1

@@ -54,12 +54,20 @@ def _ws(device, nbytes):
 BIG_M = 192   # rows from which a linear goes to the library GEMM instead of the M <= 128 latency kernel (B >= 4 images)
 
 
-def _linear_raw(x2d, lin, transposed, bias, residual, act, want_pre):
-    """y = x W^T (+ b) (QuickGELU) (+ residual) with bf16 operands and fp32 accumulate / output.  transposed: y = x W (backward)."""
+def _gelu_grad(pre):
+    s = torch.sigmoid(1.702 * pre)
+    return s + 1.702 * pre * s * (1 - s)
+
+
+def _linear_raw(x2d, lin, transposed, bias, residual, act, want_pre, gelu_pre=None):
+    """y = x W^T (+ b) (QuickGELU) (+ residual) with bf16 operands and fp32 accumulate / output.  transposed: y = x W (backward);
+    gelu_pre (backward only): x is multiplied by QuickGELU'(gelu_pre) first (folded into the packing pass of the kernel)."""
     lib = L.load()
     M = x2d.shape[0]
     N, K = (lin.K, lin.N) if transposed else (lin.N, lin.K)
     if M >= BIG_M:
+        if gelu_pre is not None:
+            x2d = x2d * _gelu_grad(gelu_pre)
         # batched scoring (ShapeGen codebook, pose retrieval: hundreds of renders per call): a plain GEMM, where hipBLASLt is the
         # right tool; the hand-written kernel streams the weights once per 128 rows
         w = lin.wd if transposed else lin.wd.t()
@@ -80,6 +88,10 @@ def _linear_raw(x2d, lin, transposed, bias, residual, act, want_pre):
     for m0 in range(0, M, 128):
         m1 = min(M, m0 + 128)
         off = lambda t, cols: None if t is None else t.data_ptr() + m0 * cols * 4
+        if gelu_pre is not None:
+            L.check(lib.avc_vit_linear_bwd_gelu(off(x2d, K), off(gelu_pre, K), L.ptr(wp), off(y, N), m1 - m0, N, K, L.ptr(ws), L.stream()),
+                    "avc_vit_linear_bwd_gelu")
+            continue
         L.check(lib.avc_vit_linear(off(x2d, K), L.ptr(wp), L.ptr(bias), off(residual, N), off(y, N), off(pre, N),
                                    m1 - m0, N, K, act, L.ptr(ws), L.stream()), "avc_vit_linear")
     return y, pre
@@ -101,11 +113,8 @@ class LinearFn(torch.autograd.Function):
         lin = ctx.lin
         shp = dy.shape
         d2 = dy.reshape(-1, lin.N).contiguous().float()
-        if ctx.act:
-            (pre,) = ctx.saved_tensors
-            s = torch.sigmoid(1.702 * pre)
-            d2 = d2 * (s + 1.702 * pre * s * (1 - s))
-        dx, _ = _linear_raw(d2.contiguous(), lin, True, None, None, 0, False)
+        pre = ctx.saved_tensors[0] if ctx.act else None      # QuickGELU'(pre) is applied inside the GEMM's packing pass
+        dx, _ = _linear_raw(d2, lin, True, None, None, 0, False, gelu_pre=pre)
         dres = dy if ctx.has_res else None
         return dx.reshape(*shp[:-1], lin.K), None, None, dres
 

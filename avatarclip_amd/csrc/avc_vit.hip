@@ -14,14 +14,27 @@
 
 // X[M,K] fp32 -> bf16 A-operand fragments [m-tile][k-step][lane][8] (lane (i,h) holds X[32m+i][16s+8h+j]): the GEMM then
 // reads its activations with the same coalesced 16-B-per-lane loads as its weights.
-__global__ __launch_bounds__(64) void vit_pack_x_kernel(const float* __restrict__ X, b8* __restrict__ xs, int M, int K) {
+// With `pre` (the pre-activation of a QuickGELU layer, same shape as X) the rows are multiplied by gelu'(pre) on the way: the
+// backward of the activation is folded into the packing pass of the GEMM that follows it (dX = (dY * gelu'(pre)) W).
+__global__ __launch_bounds__(64) void vit_pack_x_kernel(const float* __restrict__ X, const float* __restrict__ pre,
+                                                        b8* __restrict__ xs, int M, int K) {
   const int s = blockIdx.x, m = blockIdx.y, KS = K >> 4;
   const int lane = threadIdx.x, n = lane & 31, h = lane >> 5;
   const int row = 32 * m + n;
   b8 xf;
   if (row < M) {
     const f4* xp = reinterpret_cast<const f4*>(X + (long)row * K + 16 * s + 8 * h);
-    const f4 a = xp[0], b = xp[1];
+    f4 a = xp[0], b = xp[1];
+    if (pre) {
+      const f4* pp = reinterpret_cast<const f4*>(pre + (long)row * K + 16 * s + 8 * h);
+      const f4 pa = pp[0], pb = pp[1];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float sa = sigmoidf_(1.702f * pa[j]), sb = sigmoidf_(1.702f * pb[j]);
+        a[j] *= sa + 1.702f * pa[j] * sa * (1.f - sa);
+        b[j] *= sb + 1.702f * pb[j] * sb * (1.f - sb);
+      }
+    }
     xf[0] = (__bf16)a[0]; xf[1] = (__bf16)a[1]; xf[2] = (__bf16)a[2]; xf[3] = (__bf16)a[3];
     xf[4] = (__bf16)b[0]; xf[5] = (__bf16)b[1]; xf[6] = (__bf16)b[2]; xf[7] = (__bf16)b[3];
   } else {
@@ -93,8 +106,8 @@ extern "C" long avc_vit_workspace_bytes(int M, int K) {
   return mt * (K / 16) * 1024L;
 }
 
-extern "C" int avc_vit_linear(const float* x, const void* w_packed, const float* bias, const float* residual, float* y,
-                              float* y_pre, int M, int N, int K, int act, void* workspace, void* stream) {
+static int vit_linear_impl(const float* x, const float* x_gelu_pre, const void* w_packed, const float* bias, const float* residual,
+                           float* y, float* y_pre, int M, int N, int K, int act, void* workspace, void* stream) {
   if (M <= 0) return 0;
   if ((N & 31) || (K & 15) || M > 32 * VIT_MAX_MT) {
     avc_set_error("avc_vit_linear: need N % 32 == 0, K % 16 == 0, M <= 128");
@@ -104,7 +117,7 @@ extern "C" int avc_vit_linear(const float* x, const void* w_packed, const float*
   hipStream_t s = (hipStream_t)stream;
   const int mt = (M + 31) / 32;
   b8* xs = (b8*)workspace;
-  hipLaunchKernelGGL(vit_pack_x_kernel, dim3(K / 16, mt), dim3(64), 0, s, x, xs, M, K);
+  hipLaunchKernelGGL(vit_pack_x_kernel, dim3(K / 16, mt), dim3(64), 0, s, x, x_gelu_pre, xs, M, K);
   const dim3 grid(N / 32), block(64 * VIT_WAVES);
   const b8* wp = (const b8*)w_packed;
   const int lds = VIT_WAVES * mt * 4096;
@@ -121,6 +134,15 @@ extern "C" int avc_vit_linear(const float* x, const void* w_packed, const float*
     default: hipLaunchKernelGGL((vit_linear_kernel<4>), grid, block, lds, s, xs, wp, bias, residual, y, y_pre, M, N, K, act); break;
   }
   return avc_check_launch("avc_vit_linear");
+}
+
+extern "C" int avc_vit_linear(const float* x, const void* w_packed, const float* bias, const float* residual, float* y,
+                              float* y_pre, int M, int N, int K, int act, void* workspace, void* stream) {
+  return vit_linear_impl(x, nullptr, w_packed, bias, residual, y, y_pre, M, N, K, act, workspace, stream);
+}
+extern "C" int avc_vit_linear_bwd_gelu(const float* dy, const float* pre, const void* wt_packed, float* dx, int M, int N, int K,
+                                       void* workspace, void* stream) {
+  return vit_linear_impl(dy, pre, wt_packed, nullptr, nullptr, dx, nullptr, M, N, K, 0, workspace, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------

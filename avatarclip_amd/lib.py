@@ -31,6 +31,7 @@ _SIGS = {
     "avc_mc_emit": (c_int, [P, c_int, c_int, c_int, c_float, P, P, P, P, P, P, P, P, P]),
     "avc_text_attention_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "avc_vit_linear": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "avc_vit_linear_bwd_gelu": (c_int, [P, P, P, P, c_int, c_int, c_int, P, P]),
     "avc_vit_workspace_bytes": (c_long, [c_int, c_int]),
     "avc_vit_attention_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "avc_vit_attention_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),

@@ -127,6 +127,10 @@ int avc_mc_emit(const float* u, int nx, int ny, int nz, float iso, const int* vf
 int avc_vit_linear(const float* x, const void* w_packed, const float* bias, const float* residual, float* y,
                    float* y_pre, int M, int N, int K, int act, void* workspace /* avc_vit_workspace_bytes(M, K) */,
                    void* stream);
+/* backward through a QuickGELU layer and the linear in front of it in one call: dx[M,N] = (dy[M,K] * gelu'(pre[M,K])) W, with
+ * the packed W^T (N = the layer's input width, K = its output width); the activation derivative is applied while dy is packed. */
+int avc_vit_linear_bwd_gelu(const float* dy, const float* pre, const void* wt_packed, float* dx, int M, int N, int K,
+                            void* workspace, void* stream);
 /* bytes of the bf16 fragment copy of x that avc_vit_linear builds in `workspace` */
 long avc_vit_workspace_bytes(int M, int K);
 /* multi-head self-attention of ResidualAttentionBlock over T=50 tokens, head dim 64: qkv[B,T,3W] -> out[B,T,W] */

@@ -147,7 +147,7 @@ __device__ __forceinline__ void weight_grad_body(char* lds, const b8* __restrict
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       if (wa + WA * i < ta_n) {
-        if (bias_partial && wb == 0) {
+        if (bias_partial && wb == i) {   // the bias row sums of A tile i are the job of the wave column wb = i (balanced across waves)
 #pragma unroll
           for (int j = 0; j < 8; ++j) bsum[i] += (float)a[i][0][j] + (float)a[i][1][j];
         }
@@ -179,7 +179,7 @@ __device__ __forceinline__ void weight_grad_body(char* lds, const b8* __restrict
         d4[q] = v;
       }
     }
-    if (bias_partial && wb == 0) {
+    if (bias_partial && wb == i) {
       const float s = xhalf_sum(bsum[i]);
       if (lane < 32) bias_partial[(long)split * bias_elems + ta * 32 + lane] = s;
     }
@@ -257,11 +257,13 @@ __device__ __forceinline__ void weight_grad_body_9x9(char* lds, const b8* __rest
       for (int i = 0; i < 2; ++i) { a[i][0] = f16_to_bf16(a[i][0]); a[i][1] = f16_to_bf16(a[i][1]); }
       if (has_x) { sa[0] = f16_to_bf16(sa[0]); sa[1] = f16_to_bf16(sa[1]); }
     }
-    if (bias_partial && wb == 0) {
+    if (bias_partial) {   // wave (wa, wb): row sums of A tile wa + 4 wb
 #pragma unroll
       for (int i = 0; i < 2; ++i)
+        if (wb == i) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bsum[i] += (float)a[i][0][j] + (float)a[i][1][j];
+          for (int j = 0; j < 8; ++j) bsum[i] += (float)a[i][0][j] + (float)a[i][1][j];
+        }
     }
     if (bias_partial && wv == 4) {   // wave (0, 1): row sums of the ninth A tile
 #pragma unroll
@@ -316,9 +318,9 @@ __device__ __forceinline__ void weight_grad_body_9x9(char* lds, const b8* __rest
   if (has_x) store_tile(8, wb + 2 * xk, ex[0]);
   if (wb == 1) store_tile(8, 2 * wa, ex[1]);
   if (bias_partial) {
-    if (wb == 0) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i) {
+      if (wb == i) {
         const float sx = xhalf_sum(bsum[i]);
         if (lane < 32) bias_partial[(long)split * bias_elems + (wa + 4 * i) * 32 + lane] = sx;
       }

@@ -27,6 +27,13 @@ for (ta, tb, tya, tyb, count) in ((8, 2, 1, 0, 2), (8, 2, 0, 1, 1), (8, 8, 1, 0,
     tot += ms * count
     print("ta %d tb %d types %d/%d  x%d: %.3f ms for %.2f GB of tiles: %.0f GB/s" % (ta, tb, tya, tyb, count, ms, gb, gb / ms * 1e3), flush=True)
 print("sum over the real pair list: %.3f ms" % tot)
+# cost of the bias row sums (16 cvt + 16 add per A tile and block on the waves with wb = 0): the same 8 x 8 pair with and without
+for boff in (-1, 0):
+    pairs = np.array([[0, 8, 20, 8, 0, boff, 1, 0]], dtype=np.int32)
+    run(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); run(); e1.record(); torch.cuda.synchronize()
+    print("8 x 8 pair (bf16 x f16), bias sums %s: %.3f ms" % ("on" if boff >= 0 else "off", e0.elapsed_time(e1)))
 # the same 8 x 8 pair on random data (zeros above): does the data matter (toggle power, clocks)?
 panels.copy_(torch.randint(-2000, 2000, panels.shape, dtype=torch.int16, device=dev))
 pairs = np.array([[0, 8, 20, 8, 0, -1, 1, 0]], dtype=np.int32)

@@ -244,6 +244,15 @@ __device__ __forceinline__ void pe_to_frags_f16(const PE& pe, const float (&x)[3
 }
 
 static inline int avc_div_up(int a, int b) { return (a + b - 1) / b; }
+// hipFuncSetAttribute applies to the CURRENT device only: the launchers raise their dynamic-LDS limit once per device
+// (`seen` = the launcher's own bit set of device ordinals)
+static inline bool avc_first_use_on_device(unsigned long long& seen) {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) return true;
+  if ((seen >> d) & 1ull) return false;
+  seen |= 1ull << d;
+  return true;
+}
 
 // error plumbing for the C ABI
 extern "C" const char* avc_last_error();

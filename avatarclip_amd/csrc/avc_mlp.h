@@ -266,41 +266,49 @@ __device__ __forceinline__ void layer2_s(ST& st, const V* __restrict__ blob, int
 // ---------------------------------------------------------------------------------------------------------------
 // Operand panels of the training path (mirrored by packing.py: build_layout).  Every operand of every weight-gradient
 // product is stored ONCE, in the layout the producing wavefront holds it in: per 32-point block and 32-feature tile the two
-// B-operand fragments [k-step e][lane][8 x 16 bit] (lane = point + 32 * half), 2 KiB per tile.  Forward-type operands
-// (h, g_a, feature, r, [x,n], PE) are f16 and written by the forward kernel, gradient-type operands (gbar_h, abar, delta,
-// ybar) are bf16 and written by the backward kernel; the sweeps of both kernels read tiles back as they are (no
-// transposition), the weight-gradient kernel transposes them on the matrix core when it loads them (avc_wgrad.hip).
+// B-operand fragments [k-step e][lane][8 x 16 bit] (lane = point + 32 * half), 2 KiB per tile.  Two REGIONS with their own
+// block stride:
+//   F region (P_* indices, P_TILES tiles per block): forward-type operands (h, g_a, feature, r, [x,n], PE), f16, written by
+//            the forward kernel for every block of the ray set and kept until the backward pass;
+//   G region (G_* indices, G_TILES tiles per block): gradient-type operands (gbar_h, abar, delta, ybar), bf16, written by the
+//            backward kernel.  The backward pass walks the ray set in SLABS (backward kernel + weight-gradient kernel per
+//            slab), so the G region holds one slab and is reused: the gradient-type half of the operands never exists for
+//            more than a slab at a time (512^2 x 64 spp: 87 GiB of F panels + 23 GiB of G panels instead of 177 GiB).
+// The sweeps of both kernels read tiles back as they are (no transposition), the weight-gradient kernel transposes them with
+// the LDS transpose read when it loads them (avc_wgrad.hip).
 // ---------------------------------------------------------------------------------------------------------------
 template <class N>
 struct PanelLayout {
   static constexpr int HT = N::HT, ST = N::ST, NM = N::NMID, NC = N::NCMID;
-  // (hs, pe) and (gbar_hs, gbar_h0) are adjacent: the last layer's input is [hs | pe], so its weight-gradient products read
-  // them as ONE run of ST + 2 tiles
-  static constexpr int P_H1 = 0;                    // h1                                          f16, forward
+  // ---- F region.  (hs, pe) are adjacent: the last layer's input is [hs | pe], so its weight-gradient product reads them as
+  // ONE run of ST + 2 tiles; (feature, [x,n]) likewise for the first colour layer
+  static constexpr int P_H1 = 0;                    // h1
   static constexpr int P_HM = P_H1 + HT;            // hm[NM]
   static constexpr int P_HS = P_HM + NM * HT;       // hs (ST)
   static constexpr int P_H0 = P_HS + ST;            // pe values (2 tiles)
-  static constexpr int P_GBH1 = P_H0 + 2;           // gbar_h1                                     bf16, backward
-  static constexpr int P_GBHM = P_GBH1 + HT;        // gbar_hm[NM]
-  static constexpr int P_GBHS = P_GBHM + NM * HT;   // gbar_hs (ST)
-  static constexpr int P_GB0 = P_GBHS + ST;         // gbar_h0 (2)
-  static constexpr int P_GA1 = P_GB0 + 2;           // g_a1                                        f16, forward
+  static constexpr int P_GA1 = P_H0 + 2;            // g_a1
   static constexpr int P_GAM = P_GA1 + HT;          // g_am[NM]
   static constexpr int P_GAS = P_GAM + NM * HT;     // g_as (ST)
-  static constexpr int P_AB1 = P_GAS + ST;          // abar_1                                      bf16, backward
-  static constexpr int P_ABM = P_AB1 + HT;          // abar_m[NM]
-  static constexpr int P_ABS = P_ABM + NM * HT;     // abar_s (ST)
-  static constexpr int P_DFEAT = P_ABS + ST;        // ybar[1:] (HT)                               bf16, backward
-  static constexpr int P_SDF = P_DFEAT + HT;        // feature 0 = d_sdf (1)                       bf16, backward
-  static constexpr int P_ONE = P_SDF + 1;           // feature 0 = 1 (1)                           bf16, backward
-  static constexpr int P_FEAT = P_ONE + 1;          // feature (HT)                                f16, forward
-  static constexpr int P_XN = P_FEAT + HT;          // [x, n] (1)                                  f16, forward
-  static constexpr int P_R1 = P_XN + 1;             // r1 (HT)                                     f16, forward
-  static constexpr int P_R2 = P_R1 + HT;            // r2 (HT, only NC==1)                         f16, forward
-  static constexpr int P_D1 = P_R2 + NC * HT;       // delta1 (HT)                                 bf16, backward
-  static constexpr int P_D2 = P_D1 + HT;            // delta2 (HT, only NC==1)
-  static constexpr int P_DO = P_D2 + NC * HT;       // delta_o (1)
-  static constexpr int P_TILES = P_DO + 1;
+  static constexpr int P_FEAT = P_GAS + ST;         // feature (HT)
+  static constexpr int P_XN = P_FEAT + HT;          // [x, n] (1)
+  static constexpr int P_R1 = P_XN + 1;             // r1 (HT)
+  static constexpr int P_R2 = P_R1 + HT;            // r2 (HT, only NC==1)
+  static constexpr int P_TILES = P_R2 + NC * HT;    // tiles per block of the F region
+  // ---- G region.  (gbar_hs, gbar_h0) and (ybar[1:], d_sdf) are adjacent for the same reason
+  static constexpr int G_GBH1 = 0;                  // gbar_h1
+  static constexpr int G_GBHM = G_GBH1 + HT;        // gbar_hm[NM]
+  static constexpr int G_GBHS = G_GBHM + NM * HT;   // gbar_hs (ST)
+  static constexpr int G_GB0 = G_GBHS + ST;         // gbar_h0 (2)
+  static constexpr int G_AB1 = G_GB0 + 2;           // abar_1
+  static constexpr int G_ABM = G_AB1 + HT;          // abar_m[NM]
+  static constexpr int G_ABS = G_ABM + NM * HT;     // abar_s (ST)
+  static constexpr int G_DFEAT = G_ABS + ST;        // ybar[1:] (HT)
+  static constexpr int G_SDF = G_DFEAT + HT;        // feature 0 = d_sdf (1)
+  static constexpr int G_ONE = G_SDF + 1;           // feature 0 = 1 (1)
+  static constexpr int G_D1 = G_ONE + 1;            // delta1 (HT)
+  static constexpr int G_D2 = G_D1 + HT;            // delta2 (HT, only NC==1)
+  static constexpr int G_DO = G_D2 + NC * HT;       // delta_o (1)
+  static constexpr int G_TILES = G_DO + 1;          // tiles per block of the G region
   static constexpr int MASK_U16 = 2 * HT * 64;      // ReLU masks of r1 / r2 per 32-point block: [layer][tile][lane] x 16 bits
 };
 // the no-grad forward parks only what its own normal sweep reads back (h1, hm, feature), in a per-wavefront slot it reuses

@@ -4,7 +4,7 @@
 //
 //   avc_render_points_bwd : one wavefront per 32 points.  NOTHING of the forward pass is recomputed: the forward kernel
 //        (avc_render_points_fwd_train) left h_l, g_a,l, the ReLU masks and the colours in the block's operand panels
-//        (csrc/avc_mlp.h: PanelLayout).  This kernel runs the colour backward (phase D), the second-order sweep (i) (phase E)
+//        (csrc/avc_mlp.h: PanelLayout, F region; this kernel writes the G region of the current slab).  This kernel runs the colour backward (phase D), the second-order sweep (i) (phase E)
 //        and the reverse sweep (ii) (phase F) on bf16 operands with fp32 accumulation, reads sigma's argument / g_a / gbar_h
 //        back from the panels as fragments (no transposition) and writes the gradient-type operands of the weight-gradient
 //        products (gbar_h, abar, delta, ybar) next to them.  The second-order term abar' is not stored: the reverse sweep
@@ -46,7 +46,8 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
                                                                const float* __restrict__ T0,
                                                                const float* __restrict__ d_sdf, const float* __restrict__ d_normal,
                                                                const float* __restrict__ d_rgb, const float* __restrict__ rgb_fwd,
-                                                               char* __restrict__ panels, const unsigned short* __restrict__ masks) {
+                                                               const char* __restrict__ fpanels, char* __restrict__ gpanels,
+                                                               const unsigned short* __restrict__ masks) {
   typedef PanelLayout<N> L;
   constexpr AvcOffsets o = Off<N>::value;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -71,8 +72,11 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
     const int h = lane >> 5, p = lane & 31;
     sg.lane = lane;
     const long blk = blk0 + wv;
-    // wavefronts past the end walk the tile sequence for the barriers and write to the sink block (index nblk)
-    const PanelPtr tiles = panel_ptr(panels + (blk < nblk ? blk : nblk) * (long)L::P_TILES * 2048, lane);
+    // wavefronts past the end walk the tile sequence for the barriers and write to the sink block (index nblk) of the G region
+    // (what they read from block nblk of the F region -- the next slab's first block or the forward's sink -- is discarded)
+    const long bsel = blk < nblk ? blk : nblk;
+    const PanelPtr ftiles = panel_ptr(const_cast<char*>(fpanels) + bsel * (long)L::P_TILES * 2048, lane);   // forward-type operands: read only
+    const PanelPtr tiles = panel_ptr(gpanels + bsel * (long)L::G_TILES * 2048, lane);                       // gradient-type operands of this slab
     const AVC_GLOBAL unsigned short* mk = as_global(masks) + (blk < nblk ? blk : nblk) * (long)L::MASK_U16 + lane;
     long i = blk * 32 + p;
     const bool valid = i < npts;
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
         const float dr = (ch < 6) ? d_rgb[6 * i + (ch < 6 ? ch : 0)] * vmask : 0.f;
         dof[0][r] = (__bf16)(dr * c * (1.f - c));
       }
-      tile_store<false>(tiles, L::P_DO, dof[0], zero_frag<b8>());
+      tile_store<false>(tiles, L::G_DO, dof[0], zero_frag<b8>());
       // ReLU masks of r1 / r2 (16 bits per tile and lane, written by the forward kernel)
       unsigned m1[N::HT], m2[N::HT];
 #pragma unroll
@@ -111,10 +115,10 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
       b8 dl[N::HK];
       b8 d1[N::HK];
       if constexpr (N::NCMID == 1) {
-        layer_s<b8, 1, N::HT>(sg, Wb, o.v[OFF_CHT], nxt<N, OFF_CM0T>(sg, Wb, o), dof, AVC_RELU_BWD(dl, m2, L::P_D2));
-        layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_CM0T], nxt<N, OFF_C0T>(sg, Wb, o), dl, AVC_RELU_BWD(d1, m1, L::P_D1));
+        layer_s<b8, 1, N::HT>(sg, Wb, o.v[OFF_CHT], nxt<N, OFF_CM0T>(sg, Wb, o), dof, AVC_RELU_BWD(dl, m2, L::G_D2));
+        layer_s<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_CM0T], nxt<N, OFF_C0T>(sg, Wb, o), dl, AVC_RELU_BWD(d1, m1, L::G_D1));
       } else {
-        layer_s<b8, 1, N::HT>(sg, Wb, o.v[OFF_CHT], nxt<N, OFF_C0T>(sg, Wb, o), dof, AVC_RELU_BWD(d1, m1, L::P_D1));
+        layer_s<b8, 1, N::HT>(sg, Wb, o.v[OFF_CHT], nxt<N, OFF_C0T>(sg, Wb, o), dof, AVC_RELU_BWD(d1, m1, L::G_D1));
       }
       // d r0 = C0^T delta1: HT feature tiles (ybar[1:], kept for the reverse sweep), then the [x,n] tile (rows 3,4,5 = d n)
       float dn_acc[3] = {0.f, 0.f, 0.f};
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
           b8 f0, f1;
           _Pragma("unroll") for (int j = 0; j < 8; ++j) { f0[j] = (__bf16)acc[j]; f1[j] = (__bf16)acc[8 + j]; }
           pin2(f0, f1);
-          tile_store<true>(tiles, L::P_DFEAT + (t < N::HT ? t : 0), f0, f1);
+          tile_store<true>(tiles, L::G_DFEAT + (t < N::HT ? t : 0), f0, f1);
         } else {
           dn_acc[0] = acc[3]; dn_acc[1] = acc[0]; dn_acc[2] = acc[1];
         }
@@ -142,8 +146,8 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
     {   // operand tiles with a single live feature (slot (half 0, j = 0) = feature 0): d_sdf and the constant 1 (row 0 of the last layer)
       b8 fs = zero_frag<b8>(), fo = zero_frag<b8>();
       if (h == 0) { fs[0] = (__bf16)dsdf; fo[0] = (__bf16)vmask; }
-      tile_store<false>(tiles, L::P_SDF, fs, zero_frag<b8>());
-      tile_store<false>(tiles, L::P_ONE, fo, zero_frag<b8>());
+      tile_store<false>(tiles, L::G_SDF, fs, zero_frag<b8>());
+      tile_store<false>(tiles, L::G_ONE, fo, zero_frag<b8>());
     }
     // ------------------------------------------------------------------ phase E: second-order sweep (i) (bf16)
     {
@@ -154,29 +158,29 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
 #pragma unroll
         for (int q = 0; q < 24; ++q) gb0[q >> 3][q & 7] = (__bf16)(pe4.d[q] * nbar[q % 3]);
       }
-      tile_store<false>(tiles, L::P_GB0, gb0[0], gb0[1]);
-      tile_store<false>(tiles, L::P_GB0 + 1, gb0[2], zero_frag<b8>());
+      tile_store<false>(tiles, L::G_GB0, gb0[0], gb0[1]);
+      tile_store<false>(tiles, L::G_GB0 + 1, gb0[2], zero_frag<b8>());
       // gbar_a = W gbar_h(in); gbar_h(out) = gbar_a * sigma(h_out)
 #define AVC_SECOND(OUT, PH, PT)                                                                             \
-  AVC_PRE(return tile_load<true, h8>(tiles, (PH) + t);),                                                     \
+  AVC_PRE(return tile_load<true, h8>(ftiles, (PH) + t);),                                                    \
   AVC_EPID(FragPair<h8>, _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                     \
             OUT[2 * t][j] = (__bf16)(acc[j] * sig_from_h((float)d.a0[j]));                                   \
             OUT[2 * t + 1][j] = (__bf16)(acc[8 + j] * sig_from_h((float)d.a1[j])); }                         \
           pin2(OUT[2 * t], OUT[2 * t + 1]);                                                                  \
           tile_store<true>(tiles, (PT) + t, OUT[2 * t], OUT[2 * t + 1]);)
       b8 gb1[N::HK];
-      layer_sqd<b8, 3, N::HT>(sg, Wb, o.v[OFF_W0G], nxt<N, OFF_WM0>(sg, Wb, o), gb0, AVC_SECOND(gb1, L::P_H1, L::P_GBH1));
+      layer_sqd<b8, 3, N::HT>(sg, Wb, o.v[OFF_W0G], nxt<N, OFF_WM0>(sg, Wb, o), gb0, AVC_SECOND(gb1, L::P_H1, L::G_GBH1));
       b8 gbm[N::HK];
       b8 gbs[N::SK];
       if constexpr (N::NMID == 2) {
-        layer_sqd<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wb, o), gb1, AVC_SECOND(gbm, L::P_HM, L::P_GBHM));
+        layer_sqd<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wb, o), gb1, AVC_SECOND(gbm, L::P_HM, L::G_GBHM));
         b8 gbm1[N::HK];
         layer_sqd<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wb, o), gbm,
-                                    AVC_SECOND(gbm1, L::P_HM + N::HT, L::P_GBHM + N::HT));
-        layer_sqd<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WS], nxt<N, OFF_WLT>(sg, Wb, o), gbm1, AVC_SECOND(gbs, L::P_HS, L::P_GBHS));
+                                    AVC_SECOND(gbm1, L::P_HM + N::HT, L::G_GBHM + N::HT));
+        layer_sqd<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WS], nxt<N, OFF_WLT>(sg, Wb, o), gbm1, AVC_SECOND(gbs, L::P_HS, L::G_GBHS));
       } else {
-        layer_sqd<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wb, o), gb1, AVC_SECOND(gbm, L::P_HM, L::P_GBHM));
-        layer_sqd<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WS], nxt<N, OFF_WLT>(sg, Wb, o), gbm, AVC_SECOND(gbs, L::P_HS, L::P_GBHS));
+        layer_sqd<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wb, o), gb1, AVC_SECOND(gbm, L::P_HM, L::G_GBHM));
+        layer_sqd<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WS], nxt<N, OFF_WLT>(sg, Wb, o), gbm, AVC_SECOND(gbs, L::P_HS, L::G_GBHS));
       }
     }
     // ------------------------------------------------------------------ phase F: reverse sweep (ii) (bf16)
@@ -185,17 +189,17 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
       b8 dfeat[N::HK];
 #pragma unroll
       for (int t = 0; t < N::HT; ++t) {
-        const FragPair<b8> d = tile_load<true, b8>(tiles, L::P_DFEAT + t);
+        const FragPair<b8> d = tile_load<true, b8>(tiles, L::G_DFEAT + t);
         dfeat[2 * t] = d.a0;
         dfeat[2 * t + 1] = d.a1;
       }
 #define AVC_LOAD3(PH, PB, PG)                                                                               \
-  AVC_PRE(PF3 d; { const FragPair<h8> a = tile_load<true, h8>(tiles, (PH) + t); d.h0 = a.a0; d.h1 = a.a1; }  \
+  AVC_PRE(PF3 d; { const FragPair<h8> a = tile_load<true, h8>(ftiles, (PH) + t); d.h0 = a.a0; d.h1 = a.a1; } \
           { const FragPair<b8> a = tile_load<true, b8>(tiles, (PB) + t); d.b0 = a.a0; d.b1 = a.a1; }         \
-          { const FragPair<h8> a = tile_load<true, h8>(tiles, (PG) + t); d.g0 = a.a0; d.g1 = a.a1; } return d;)
+          { const FragPair<h8> a = tile_load<true, h8>(ftiles, (PG) + t); d.g0 = a.a0; d.g1 = a.a1; } return d;)
       // ubar[:SKIP]/sqrt2 = (W_last[1:,:]^T dfeat + W_last[0,:] d_sdf)/sqrt2 ; 1/sqrt2 is folded into both packs
       layer_sq<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WLT], nxt<N, OFF_WST>(sg, Wb, o), dfeat,
-        AVC_LOAD3(L::P_HS, L::P_GBHS, L::P_GAS), AVC_EPID(PF3,
+        AVC_LOAD3(L::P_HS, L::G_GBHS, L::P_GAS), AVC_EPID(PF3,
         float wa[16];
         load16(T + o.v[OFF_WL0_ACC], t, h, wa);
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
           as_[2 * t + 1][j] = (__bf16)(second_term((float)d.b1[j], (float)d.g1[j], s1) + (acc[8 + j] + wa[8 + j] * dsdfS) * s1);
         }
         pin2(as_[2 * t], as_[2 * t + 1]);
-        tile_store<false>(tiles, L::P_ABS + t, as_[2 * t], as_[2 * t + 1]);
+        tile_store<false>(tiles, L::G_ABS + t, as_[2 * t], as_[2 * t + 1]);
       ));
       // hbar(prev) = W^T abar(cur); abar(prev) = abar'(prev) + hbar * sigma(h_prev)
 #define AVC_REVERSE(OUT, PH, PB, PG, PT)                                                                    \
@@ -220,29 +224,26 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
       const Next first = nxt<N, OFF_CHT>(sg, Wb0, o);   // prefetch the first tile of the next block iteration
       if constexpr (N::NMID == 2) {
         layer_sq<b8, N::SK, N::HT>(sg, Wb, o.v[OFF_WST], nxt<N, OFF_WM1T>(sg, Wb, o), as_,
-                                   AVC_REVERSE(am, L::P_HM + N::HT, L::P_GBHM + N::HT, L::P_GAM + N::HT, L::P_ABM + N::HT));
+                                   AVC_REVERSE(am, L::P_HM + N::HT, L::G_GBHM + N::HT, L::P_GAM + N::HT, L::G_ABM + N::HT));
         layer_sq<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM1T], nxt<N, OFF_WM0T>(sg, Wb, o), am,
-                                   AVC_REVERSE(am0, L::P_HM, L::P_GBHM, L::P_GAM, L::P_ABM));
-        layer_sq<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0T], first, am0, AVC_REVERSE(am, L::P_H1, L::P_GBH1, L::P_GA1, L::P_AB1));
+                                   AVC_REVERSE(am0, L::P_HM, L::G_GBHM, L::P_GAM, L::G_ABM));
+        layer_sq<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0T], first, am0, AVC_REVERSE(am, L::P_H1, L::G_GBH1, L::P_GA1, L::G_AB1));
       } else {
         layer_sq<b8, N::SK, N::HT>(sg, Wb, o.v[OFF_WST], nxt<N, OFF_WM0T>(sg, Wb, o), as_,
-                                   AVC_REVERSE(am, L::P_HM, L::P_GBHM, L::P_GAM, L::P_ABM));
-        layer_sq<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0T], first, am, AVC_REVERSE(am0, L::P_H1, L::P_GBH1, L::P_GA1, L::P_AB1));
+                                   AVC_REVERSE(am, L::P_HM, L::G_GBHM, L::P_GAM, L::G_ABM));
+        layer_sq<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0T], first, am, AVC_REVERSE(am0, L::P_H1, L::G_GBH1, L::P_GA1, L::G_AB1));
       }
     }
   }
 }
 
-extern "C" int avc_bwd_panel_tiles(int net) {
-  return net == AVC_NET_FULL ? PanelLayout<NetFull>::P_TILES : PanelLayout<NetSmall>::P_TILES;
-}
-
 extern "C" int avc_render_points_bwd(int net, const float* pts, const float* rays_o, const float* rays_d, const float* z,
                                      int S, int ldz, float sample_dist, long npts, const void* wbf16, const float* tab,
                                      const int* offs, const float* d_sdf, const float* d_normal, const float* d_rgb,
-                                     const float* rgb_fwd, void* panels, const void* masks, long max_waves, void* stream) {
+                                     const float* rgb_fwd, const void* fpanels, void* gpanels, const void* masks, long max_waves,
+                                     void* stream) {
   if (npts <= 0) return 0;
-  if (!panels || !masks || !rgb_fwd) { avc_set_error("avc_render_points_bwd: panels / masks / rgb_fwd == NULL"); return 1; }
+  if (!fpanels || !gpanels || !masks || !rgb_fwd) { avc_set_error("avc_render_points_bwd: fpanels / gpanels / masks / rgb_fwd == NULL"); return 1; }
   if (!(net == AVC_NET_FULL ? offsets_match<NetFull>(offs) : offsets_match<NetSmall>(offs))) {
     avc_set_error("packed-blob offsets differ from the compiled-in table (regenerate csrc/avc_offsets_gen.h)");
     return 1;
@@ -257,18 +258,17 @@ extern "C" int avc_render_points_bwd(int net, const float* pts, const float* ray
   hipStream_t s = (hipStream_t)stream;
   const int lds_bytes = StageT<BWD_G>::LDS_BYTES + AVC_TAB_LDS_BYTES;
   if (offs[OFF_TAB_END] * 4 > AVC_TAB_LDS_BYTES) { avc_set_error("fp32 table does not fit its LDS window"); return 1; }
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_seen = 0;
+  if (avc_first_use_on_device(attr_seen)) {
     (void)hipFuncSetAttribute((const void*)mlp_bwd_kernel<NetFull>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     (void)hipFuncSetAttribute((const void*)mlp_bwd_kernel<NetSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    attr_set = true;
   }
   if (net == AVC_NET_FULL)
     hipLaunchKernelGGL((mlp_bwd_kernel<NetFull>), dim3(grid), dim3(64 * BWD_WPB), lds_bytes, s, ps, npts, (const b8*)wbf16, tab, d_sdf,
-                       d_normal, d_rgb, rgb_fwd, (char*)panels, (const unsigned short*)masks);
+                       d_normal, d_rgb, rgb_fwd, (const char*)fpanels, (char*)gpanels, (const unsigned short*)masks);
   else if (net == AVC_NET_SMALL)
     hipLaunchKernelGGL((mlp_bwd_kernel<NetSmall>), dim3(grid), dim3(64 * BWD_WPB), lds_bytes, s, ps, npts, (const b8*)wbf16, tab, d_sdf,
-                       d_normal, d_rgb, rgb_fwd, (char*)panels, (const unsigned short*)masks);
+                       d_normal, d_rgb, rgb_fwd, (const char*)fpanels, (char*)gpanels, (const unsigned short*)masks);
   else { avc_set_error("unknown net id"); return 1; }
   return avc_check_launch("avc_render_points_bwd");
 }

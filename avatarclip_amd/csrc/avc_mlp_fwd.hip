@@ -311,8 +311,11 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
 extern "C" long avc_fwd_scratch_bytes_per_wave(int net) {
   return (long)(net == AVC_NET_FULL ? ScratchLayout<NetFull>::P_TILES : ScratchLayout<NetSmall>::P_TILES) * 2048;
 }
-extern "C" int avc_panel_tiles(int net) {
+extern "C" int avc_fwd_panel_tiles(int net) {
   return net == AVC_NET_FULL ? PanelLayout<NetFull>::P_TILES : PanelLayout<NetSmall>::P_TILES;
+}
+extern "C" int avc_grad_panel_tiles(int net) {
+  return net == AVC_NET_FULL ? PanelLayout<NetFull>::G_TILES : PanelLayout<NetSmall>::G_TILES;
 }
 extern "C" int avc_mask_u16_per_block(int net) {
   return net == AVC_NET_FULL ? PanelLayout<NetFull>::MASK_U16 : PanelLayout<NetSmall>::MASK_U16;
@@ -343,11 +346,10 @@ static int launch_sdf(int net, PointSrc ps, long npts, const void* wf, const flo
   const int wpb = SDF_WPB;   // wavefronts per workgroup
   const int grid = grid_for(npts, wpb, 0x7fffffff);
   const int lds_bytes = StageT<FWD_G>::LDS_BYTES + AVC_TAB_LDS_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_seen = 0;
+  if (avc_first_use_on_device(attr_seen)) {
     hipFuncSetAttribute((const void*)mlp_sdf_kernel<NetFull>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     hipFuncSetAttribute((const void*)mlp_sdf_kernel<NetSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    attr_set = true;
   }
   if (net == AVC_NET_FULL)
     hipLaunchKernelGGL((mlp_sdf_kernel<NetFull>), dim3(grid), dim3(64 * wpb), lds_bytes, s, ps, npts, (const h8*)wf, tab,
@@ -383,11 +385,10 @@ static int launch_render(int net, PointSrc ps, long npts, const void* wf16, cons
   const int grid = grid_for(npts, FWD_WPB, (int)(maxg < 0x7fffffff ? maxg : 0x7fffffff));
   const int lds_bytes = StageT<FWD_G>::LDS_BYTES + AVC_TAB_LDS_BYTES;
   hipStream_t s = (hipStream_t)stream;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_seen = 0;
+  if (avc_first_use_on_device(attr_seen)) {
     (void)hipFuncSetAttribute((const void*)mlp_render_kernel<NetFull, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     (void)hipFuncSetAttribute((const void*)mlp_render_kernel<NetSmall, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    attr_set = true;
   }
   if (net == AVC_NET_FULL)
     hipLaunchKernelGGL((mlp_render_kernel<NetFull, TRAIN>), dim3(grid), dim3(64 * FWD_WPB), lds_bytes, s, ps, npts, (const h8*)wf16, tab,

@@ -121,11 +121,10 @@ static int vit_linear_impl(const float* x, const float* x_gelu_pre, const void* 
   const dim3 grid(N / 32), block(64 * VIT_WAVES);
   const b8* wp = (const b8*)w_packed;
   const int lds = VIT_WAVES * mt * 4096;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_seen = 0;
+  if (avc_first_use_on_device(attr_seen)) {
     (void)hipFuncSetAttribute((const void*)vit_linear_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, VIT_WAVES * 3 * 4096);
     (void)hipFuncSetAttribute((const void*)vit_linear_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, VIT_WAVES * 4 * 4096);
-    attr_set = true;
   }
   switch (mt) {
     case 1: hipLaunchKernelGGL((vit_linear_kernel<1>), grid, block, lds, s, xs, wp, bias, residual, y, y_pre, M, N, K, act); break;
@@ -336,10 +335,9 @@ extern "C" int avc_text_attention_fwd(const float* qkv, float* out, int B, int T
   if (T < 1 || T > TA_TMAX || width != heads * AT_D) { avc_set_error("avc_text_attention_fwd: 1 <= T <= 128, head dim 64"); return 1; }
   if (B <= 0) return 0;
   const size_t lds = 2 * (size_t)T * AT_LD * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_seen = 0;
+  if (avc_first_use_on_device(attr_seen)) {
     hipFuncSetAttribute((const void*)text_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TA_TMAX * AT_LD * 4);
-    attr_set = true;
   }
   hipLaunchKernelGGL(text_attn_fwd_kernel, dim3(B * heads), dim3(TA_TMAX), lds, (hipStream_t)stream, qkv, out, T, width, heads,
                      0.125f, causal);
@@ -349,10 +347,9 @@ extern "C" int avc_vit_attention_bwd(const float* qkv, const float* dout, float*
                                      void* stream) {
   if (T != AT_T || width != heads * AT_D) { avc_set_error("avc_vit_attention: built for 50 tokens, head dim 64"); return 1; }
   const size_t lds = (4 * AT_T * AT_LD + 2 * AT_T * (AT_T + 1) + 3 * AT_PARTS * 64) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_seen = 0;
+  if (avc_first_use_on_device(attr_seen)) {
     hipFuncSetAttribute((const void*)vit_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   hipLaunchKernelGGL(vit_attn_bwd_kernel, dim3(B * heads), dim3(64 * AT_PARTS), lds, (hipStream_t)stream, qkv, dout, dqkv, width, heads,
                      0.125f);

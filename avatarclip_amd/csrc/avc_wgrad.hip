@@ -6,7 +6,7 @@
 // ---------------------------------------------------------------------------------------------
 // partial[split][ta][tb] = sum over the split's 32-point blocks, sum_kappa A[blk][ta][kappa] x B[blk][tb][kappa]
 // One 8-wave workgroup per (K-split, pair).  Per block the (ta+tb) panel tiles are copied ONCE into an LDS ring by
-// global->LDS DMA (WG_DEPTH - 1 blocks in flight under the work on the current one).  The tiles arrive in the producers'
+// global->LDS DMA (ring depth - 1 blocks in flight under the work on the current one; depth: WG_DYN_DEPTH below).  The tiles arrive in the producers'
 // FRAGMENT layout (lane = point, 8 features per k-step); the contraction over points needs them feature-major (lane =
 // feature, 8 points per lane).  gfx950's LDS transpose read does that on the way into the registers: ds_read_b64_tr_b16
 // hands lane i of a 16-lane group element (i & 3) of the 8 bytes addressed by lane 4 j + (i >> 2) of the group, for j = 0..3,
@@ -26,27 +26,35 @@
 #ifndef WG_DEPTH
 #define WG_DEPTH 4   // blocks in the LDS ring: one being contracted, WG_DEPTH - 1 copies in flight
 #endif
+// WG_DYN_DEPTH = 1: the ring slot is as large as the pair's own tile set and the ring as deep as the 160 KiB of LDS allow (at most
+// WG_DEPTH_MAX): 4 blocks for the 17/18-tile products, 5 for the 15/16-tile ones, 8 for the narrow ones (9-10 tiles) -- more bytes
+// in flight per CU where a block is small.  0: WG_DEPTH slots of WG_BUF_BYTES for every pair.
+#ifndef WG_DYN_DEPTH
+#define WG_DYN_DEPTH 1
+#endif
+#define WG_DEPTH_MAX 8
+#define WG_LDS_TOTAL (WG_DYN_DEPTH ? 160 * 1024 : WG_DEPTH * WG_BUF_BYTES)
+// cache policy of the panel -> LDS copies (aux operand of global_load_lds): 0 = default, 2 = nt (streamed once, keep it out of L2's way)
+#ifndef WG_DMA_AUX
+#define WG_DMA_AUX 0
+#endif
+
+// the two operand regions (csrc/avc_mlp.h: PanelLayout): [0] = F region (forward-type, f16), [1] = G region (gradient-type, bf16)
+struct WgRegions { const char* base[2]; long stride[2]; };   // byte address of block 0 of the slab, bytes per block
 
 typedef short vs4 __attribute__((__vector_size__(4 * sizeof(short))));
 typedef __attribute__((address_space(3))) char lds_char;
 
-// wait until at most `n` of this wave's vector-memory operations are outstanding (n is wave-uniform)
+// wait until at most `n` of this wave's vector-memory operations are outstanding (n is wave-uniform; the count is an immediate)
 __device__ __forceinline__ void wait_vmcnt(int n) {
+#define WG_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
   switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    WG_W(0) WG_W(1) WG_W(2) WG_W(3) WG_W(4) WG_W(5) WG_W(6) WG_W(7) WG_W(8) WG_W(9) WG_W(10) WG_W(11) WG_W(12) WG_W(13) WG_W(14) WG_W(15)
+    WG_W(16) WG_W(17) WG_W(18) WG_W(19) WG_W(20) WG_W(21) WG_W(22) WG_W(23) WG_W(24) WG_W(25) WG_W(26) WG_W(27) WG_W(28) WG_W(29) WG_W(30)
+    WG_W(31) WG_W(32) WG_W(33) WG_W(34) WG_W(35) WG_W(36)
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // any other count: conservative
   }
+#undef WG_W
 }
 
 // operand fragment of k-step t (points 16 t .. 16 t + 15) of the tile at LDS address `tile` (+ this lane's offset): lane
@@ -67,7 +75,7 @@ __device__ __forceinline__ b8 f16_to_bf16(b8 v) {
 
 // NI x NK output tiles per wave: A tiles wa + WA i, B tiles wb + WB k
 template <int NI, int NK>
-__device__ __forceinline__ void weight_grad_body(char* lds, const b8* __restrict__ panels, int ptiles, int pa, int ta_n, int pb,
+__device__ __forceinline__ void weight_grad_body(char* lds, const WgRegions& rg, int pa, int ta_n, int pb,
                                                  int tb_n, int type_a, int type_b, long nblk, float* __restrict__ partial,
                                                  float* __restrict__ bias_partial, int out_elems, int bias_elems, int WA) {
   const int lane = threadIdx.x & 63;
@@ -79,16 +87,22 @@ __device__ __forceinline__ void weight_grad_body(char* lds, const b8* __restrict
   const int ntile = ta_n + tb_n;
   const int nchunk = ntile * 2;
   const int my_chunks = (nchunk - wv + 7) >> 3;   // DMA instructions this wave issues per block
+  const int slot_bytes = WG_DYN_DEPTH ? ntile * 2048 : WG_BUF_BYTES;
+  int depth = WG_DYN_DEPTH ? WG_LDS_TOTAL / slot_bytes : WG_DEPTH;
+  if (depth > WG_DEPTH_MAX) depth = WG_DEPTH_MAX;
   // source chunk of this lane in DMA instruction c of a tile: LDS position 64 c + lane = (p >> 2) * 16 + (2 s + h) * 4 + (p & 3)
   const int src_lo = ((lane >> 2) & 3) * 32 + 4 * (lane >> 4) + (lane & 3);   // (2 s + h) * 32 + p with p = 4 (lane >> 4) + (lane & 3)
+  // operand A lives in region type_a, operand B in region type_b (0 = F region: f16 forward-type tiles, 1 = G region: bf16)
+  const char* const base_a = (type_a ? rg.base[1] : rg.base[0]) + (long)pa * 2048;
+  const char* const base_b = (type_b ? rg.base[1] : rg.base[0]) + (long)pb * 2048;
+  const long stride_a = type_a ? rg.stride[1] : rg.stride[0], stride_b = type_b ? rg.stride[1] : rg.stride[0];
   auto issue = [&](long blk, int slot) {
-    const char* base = reinterpret_cast<const char*>(panels + blk * (long)ptiles * 128);
     for (int c = wv; c < nchunk; c += 8) {
       const int tix = c >> 1;
-      const int tile = tix < ta_n ? pa + tix : pb + (tix - ta_n);
-      const char* g = base + ((long)tile * 128 + src_lo + (c & 1) * 16) * 16;
+      const char* tb_ = tix < ta_n ? base_a + blk * stride_a + (long)tix * 2048 : base_b + blk * stride_b + (long)(tix - ta_n) * 2048;
+      const char* g = tb_ + (src_lo + (c & 1) * 16) * 16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                       (__attribute__((address_space(3))) void*)(lds + slot * WG_BUF_BYTES + c * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(lds + slot * slot_bytes + c * 1024), 16, 0, WG_DMA_AUX);
     }
   };
   // this lane's byte offset inside a tile for the transpose reads: group g = lane >> 4 = 2 hh + s, i = lane & 15 supplies
@@ -102,22 +116,22 @@ __device__ __forceinline__ void weight_grad_body(char* lds, const b8* __restrict
   float bsum[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) bsum[i] = 0.f;
-  // Ring of WG_DEPTH block buffers, ONE barrier per block: it publishes block blk (every wave has waited for its own chunks) and
+  // Ring of `depth` block buffers, ONE barrier per block: it publishes block blk (every wave has waited for its own chunks) and
   // frees the slot of block blk - 1, which the next copy then overwrites.  Raw barriers + counted vmcnt throughout:
   // __syncthreads() would drain the copies in flight.
-  for (int d = 0; d < WG_DEPTH - 1; ++d)
+  for (int d = 0; d < depth - 1; ++d)
     if (b0 + d < b1) issue(b0 + d, d);
   int slot = 0;
   for (long blk = b0; blk < b1; ++blk) {
     // LDS-DMA completes in issue order: block blk has landed when at most the chunks of the younger blocks are outstanding
     long younger = b1 - 1 - blk;
-    if (younger > WG_DEPTH - 2) younger = WG_DEPTH - 2;
+    if (younger > depth - 2) younger = depth - 2;
     wait_vmcnt((int)younger * my_chunks);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of block blk - 1 are done
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (blk + WG_DEPTH - 1 < b1) issue(blk + WG_DEPTH - 1, (slot + WG_DEPTH - 1) % WG_DEPTH);
-    lds_char* buf = (lds_char*)(lds + slot * WG_BUF_BYTES) + lane_off;
+    if (blk + depth - 1 < b1) { int ns = slot + depth - 1; if (ns >= depth) ns -= depth; issue(blk + depth - 1, ns); }
+    lds_char* buf = (lds_char*)(lds + slot * slot_bytes) + lane_off;
     b8 a[NI][2];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -160,7 +174,7 @@ __device__ __forceinline__ void weight_grad_body(char* lds, const b8* __restrict
         }
       }
     }
-    slot = (slot + 1) % WG_DEPTH;
+    if (++slot == depth) slot = 0;
   }
   float* dst = partial + (long)split * out_elems;
 #pragma unroll
@@ -192,7 +206,7 @@ __device__ __forceinline__ void weight_grad_body(char* lds, const b8* __restrict
 // the waves that have the matching B tile in registers anyway: wave (wa, 1) takes B tile 2 wa + 1 and -- one more LDS read -- 2 wa,
 // wave (0, 0) takes B tile 8: 12 accumulators at most.  B fragments are streamed one tile ahead of their MFMAs (all five at once,
 // as in the generic body, do not fit beside 12 accumulators).
-__device__ __forceinline__ void weight_grad_body_9x9(char* lds, const b8* __restrict__ panels, int ptiles, int pa, int pb, int type_a,
+__device__ __forceinline__ void weight_grad_body_9x9(char* lds, const WgRegions& rg, int pa, int pb, int type_a,
                                                      int type_b, long nblk, float* __restrict__ partial,
                                                      float* __restrict__ bias_partial, int out_elems, int bias_elems) {
   constexpr int TA = 9, TB = 9, NT = TA + TB;
@@ -204,14 +218,16 @@ __device__ __forceinline__ void weight_grad_body_9x9(char* lds, const b8* __rest
   constexpr int nchunk = NT * 2;
   const int my_chunks = (nchunk - wv + 7) >> 3;
   const int src_lo = ((lane >> 2) & 3) * 32 + 4 * (lane >> 4) + (lane & 3);
+  const char* const base_a = (type_a ? rg.base[1] : rg.base[0]) + (long)pa * 2048;
+  const char* const base_b = (type_b ? rg.base[1] : rg.base[0]) + (long)pb * 2048;
+  const long stride_a = type_a ? rg.stride[1] : rg.stride[0], stride_b = type_b ? rg.stride[1] : rg.stride[0];
   auto issue = [&](long blk, int slot) {
-    const char* base = reinterpret_cast<const char*>(panels + blk * (long)ptiles * 128);
     for (int c = wv; c < nchunk; c += 8) {
       const int tix = c >> 1;
-      const int tile = tix < TA ? pa + tix : pb + (tix - TA);
-      const char* g = base + ((long)tile * 128 + src_lo + (c & 1) * 16) * 16;
+      const char* tb_ = tix < TA ? base_a + blk * stride_a + (long)tix * 2048 : base_b + blk * stride_b + (long)(tix - TA) * 2048;
+      const char* g = tb_ + (src_lo + (c & 1) * 16) * 16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                       (__attribute__((address_space(3))) void*)(lds + slot * WG_BUF_BYTES + c * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(lds + slot * WG_BUF_BYTES + c * 1024), 16, 0, WG_DMA_AUX);
     }
   };
   const int lane_off = (((lane >> 5) * 2) * 16 + (((lane >> 4) & 1) * 2 + (lane & 1)) * 4 + ((lane & 15) >> 2)) * 16 + 8 * ((lane & 3) >> 1);
@@ -336,7 +352,7 @@ __device__ __forceinline__ void weight_grad_body_9x9(char* lds, const b8* __rest
 // x-fastest, so the tail of one pair's splits overlaps the head of the next pair's instead of draining the chip 17 times.
 #define WG_MAX_PAIRS 24
 struct WgPairs { int v[WG_MAX_PAIRS][8]; };   // pa, ta, pb, tb, out_off, bias_off (-1 = no bias), type_a, type_b
-__global__ __launch_bounds__(512) void weight_grad_all_kernel(const b8* __restrict__ panels, int ptiles, WgPairs pp, long nblk,
+__global__ __launch_bounds__(512) void weight_grad_all_kernel(WgRegions rg, WgPairs pp, long nblk,
                                                               float* __restrict__ partial, float* __restrict__ bias_partial,
                                                               int out_elems, int bias_elems) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -344,12 +360,12 @@ __global__ __launch_bounds__(512) void weight_grad_all_kernel(const b8* __restri
   float* bp = d[5] >= 0 ? bias_partial + d[5] : nullptr;
   // wide x wide: 2 x 4 (or 4 x 2) tiles per wave, the f16 operand on the side with fewer tiles per wave (it is converted to bf16
   // after the read); narrow pairs: 8 x 1 or 1 x 8 waves
-#define WG_ARGS lds, panels, ptiles, d[0], d[1], d[2], d[3], d[6], d[7], nblk, partial + d[4], bp, out_elems, bias_elems
+#define WG_ARGS lds, rg, d[0], d[1], d[2], d[3], d[6], d[7], nblk, partial + d[4], bp, out_elems, bias_elems
   if (d[1] > 1 && d[3] > 2 && d[3] <= 8) {
     if (d[7] == 0) weight_grad_body<4, 2>(WG_ARGS, 2);
     else weight_grad_body<2, 4>(WG_ARGS, 4);
   } else if (d[1] == 9 && d[3] == 9) {
-    weight_grad_body_9x9(lds, panels, ptiles, d[0], d[2], d[6], d[7], nblk, partial + d[4], bp, out_elems, bias_elems);
+    weight_grad_body_9x9(lds, rg, d[0], d[2], d[6], d[7], nblk, partial + d[4], bp, out_elems, bias_elems);
   } else if (d[1] > 1 && d[3] > 8) {
     weight_grad_body<2, 5>(WG_ARGS, 4);
   } else if (d[1] > 1) {
@@ -360,9 +376,11 @@ __global__ __launch_bounds__(512) void weight_grad_all_kernel(const b8* __restri
 #undef WG_ARGS
 }
 
-extern "C" int avc_weight_grad_all(const void* panels, int ptiles, int npairs, const int* pairs, long nblk, float* partial,
-                                   float* bias_partial, int nsplit, int out_stride, int bias_stride, void* stream) {
+extern "C" int avc_weight_grad_all(const void* fpanels, int ftiles, const void* gpanels, int gtiles, int npairs, const int* pairs,
+                                   long nblk, float* partial, float* bias_partial, int nsplit, int out_stride, int bias_stride,
+                                   void* stream) {
   if (nblk <= 0 || npairs <= 0) return 0;
+  if (!fpanels || !gpanels) { avc_set_error("avc_weight_grad_all: fpanels / gpanels == NULL"); return 1; }
   if (npairs > WG_MAX_PAIRS) { avc_set_error("avc_weight_grad_all: too many pairs"); return 1; }
   WgPairs pp;
   for (int i = 0; i < npairs; ++i) {
@@ -374,13 +392,15 @@ extern "C" int avc_weight_grad_all(const void* panels, int ptiles, int npairs, c
     }
   }
   if (nsplit < 1) nsplit = 1;
-  const int lds_bytes = WG_DEPTH * WG_BUF_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
+  const int lds_bytes = WG_LDS_TOTAL;
+  static unsigned long long attr_seen = 0;
+  if (avc_first_use_on_device(attr_seen)) {
     (void)hipFuncSetAttribute((const void*)weight_grad_all_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    attr_set = true;
   }
-  hipLaunchKernelGGL(weight_grad_all_kernel, dim3(nsplit, npairs), dim3(512), lds_bytes, (hipStream_t)stream, (const b8*)panels,
-                     ptiles, pp, nblk, partial, bias_partial, out_stride, bias_stride);
+  WgRegions rg;
+  rg.base[0] = (const char*)fpanels; rg.stride[0] = (long)ftiles * 2048;
+  rg.base[1] = (const char*)gpanels; rg.stride[1] = (long)gtiles * 2048;
+  hipLaunchKernelGGL(weight_grad_all_kernel, dim3(nsplit, npairs), dim3(512), lds_bytes, (hipStream_t)stream, rg, pp, nblk, partial,
+                     bias_partial, out_stride, bias_stride);
   return avc_check_launch("avc_weight_grad_all");
 }

@@ -73,14 +73,18 @@ class Engine:
     _by_net = weakref.WeakKeyDictionary()
     PROFILE = False               # bench.py: record (name, points, start_event, end_event) per kernel launch group
     prof_events = []
-    WG_NSPLIT = 256               # split-K workgroups per weight-gradient pair (one per CU; 512 and 1024 measured 1.5 % / 6 % slower: partial-slab traffic)
+    WG_BLOCKS_PER_SPLIT = 1024    # split-K of the weight-gradient launch: blocks per workgroup (nsplit = blocks / this, 1..256; one slab of
+                                  # 131072 blocks = 128 splits x 13 pairs = 1664 workgroups over 256 CUs)
     MAX_FWD_WAVES = 2048          # persistent grid of avc_render_points_fwd: 256 CUs x one 8-wave workgroup
     MAX_BWD_WAVES = 2048          # 256 CUs x one 8-wave workgroup
-    # operand panels (11.25 KiB per point for the full nets) per chunk of rays, capped at 70 % of the free HBM.  When one
-    # chunk holds the whole ray set (512^2 x 64 spp = 177 GiB: fits the 288 GB of an MI355X) the forward pass runs ONCE and its
-    # panels live until the backward pass; otherwise the backward re-runs the training forward chunk by chunk (the price of a
-    # ray set whose operands do not fit).  AVC_PANEL_GIB overrides the budget (tuning / test aid)
-    PANEL_BYTES_BUDGET = int(os.environ.get("AVC_PANEL_GIB", "192")) << 30
+    # Operand panels (csrc/avc_mlp.h: PanelLayout).  F region: 89 tiles = 5.6 KiB per point (full nets), written by the training
+    # forward for every block of a CHUNK of rays and kept until the backward pass; G region: 91 tiles = 5.7 KiB per point, one SLAB
+    # of SLAB_BLOCKS 32-point blocks, rewritten slab by slab by the backward pass (backward kernel + weight-gradient kernel per
+    # slab).  512^2 x 64 spp: one chunk (87 GiB of F panels) + a 23-GiB slab; 512^2 x 128 spp (BASELINE config 3 per GPU): 174 + 23
+    # GiB, still one chunk on a 288-GB MI355X.  Only when even that does not fit the budget -- min(AVC_PANEL_GIB, 80 % of the free
+    # HBM) -- the ray set is cut into chunks and the backward re-runs the training forward chunk by chunk.
+    PANEL_BYTES_BUDGET = int(os.environ.get("AVC_PANEL_GIB", "224")) << 30
+    SLAB_BLOCKS = int(os.environ.get("AVC_SLAB_BLOCKS", str(128 * 1024)))
 
     def __init__(self, spec: PK.NetSpec, device):
         if device.type != "cuda":
@@ -91,16 +95,19 @@ class Engine:
         self.dl = _DevLayout.get(spec, device)
         self.net = spec.net_id
         assert self.lib.avc_num_offsets() == PK.OFF_COUNT
-        self.ptiles = self.lib.avc_panel_tiles(self.net)
-        assert self.ptiles == self.dl.lay.panel["TILES"], "panel layout mismatch between packing.py and csrc/avc_mlp.h"
+        self.fwd_tiles = self.lib.avc_fwd_panel_tiles(self.net)      # tiles per block of the F region / of the G region
+        self.grad_tiles = self.lib.avc_grad_panel_tiles(self.net)
+        assert (self.fwd_tiles, self.grad_tiles) == (self.dl.lay.panel["FTILES"], self.dl.lay.panel["GTILES"]), \
+            "panel layout mismatch between packing.py and csrc/avc_mlp.h"
         self.mask_u16 = self.lib.avc_mask_u16_per_block(self.net)
         self.fwd_scr_bytes = self.lib.avc_fwd_scratch_bytes_per_wave(self.net)
         self._fwd_scratch = None
-        self._panels = None
+        self._fpanels = None          # F region + masks of the current chunk
+        self._gpanels = None          # G region of one slab
         self._partials = None
         self._bpartials = None
         self._masks = None
-        self._pairs_host = np.ascontiguousarray(np.asarray(self.dl.lay.pairs, dtype=np.int32).reshape(-1, 8))
+        self._pairs_host = PK.region_local_pairs(self.dl.lay)
         self._sdf_bias0 = int(self.dl.lay.pbase["sdf.b%d" % (spec.NMID + 2)])   # flat index of bias[0] of the last SDF layer
         self._packed_key = None
         self._packed = None
@@ -139,33 +146,57 @@ class Engine:
     def pack(self, flatP: torch.Tensor) -> Packed:
         return Packed(self.dl, flatP)
 
-    def _bufs(self, nblk_chunk):
-        """panels + ReLU masks for `nblk_chunk` 32-point blocks (+ 1 sink block for the wavefronts past the end)"""
-        need = (nblk_chunk + 1) * self.ptiles * 2048
-        if self._panels is None or self._panels.numel() < need:
-            self._panels = None          # release the old buffer BEFORE the larger one is allocated (peak = need, not have + need)
+    def _grow(self, attr, nbytes, dtype=torch.uint8):
+        buf = getattr(self, attr)
+        n = nbytes // torch.empty(0, dtype=dtype).element_size()
+        if buf is None or buf.numel() < n:
+            setattr(self, attr, None)    # release the old buffer BEFORE the larger one is allocated (peak = need, not have + need)
             torch.cuda.empty_cache()
-            self._panels = torch.empty(need, dtype=torch.uint8, device=self.device)
-        needm = (nblk_chunk + 1) * self.mask_u16
-        if self._masks is None or self._masks.numel() < needm:
-            self._masks = torch.empty(needm, dtype=torch.int16, device=self.device)
-        return self._panels, self._masks
+            buf = torch.empty(n, dtype=dtype, device=self.device)
+            setattr(self, attr, buf)
+        return buf
+
+    def _bufs_f(self, nblk_chunk):
+        """F panels + ReLU masks for `nblk_chunk` 32-point blocks (+ 1 sink block for the wavefronts past the end)"""
+        return (self._grow("_fpanels", (nblk_chunk + 1) * self.fwd_tiles * 2048),
+                self._grow("_masks", (nblk_chunk + 1) * self.mask_u16 * 2, torch.int16))
+
+    def _bufs_g(self, nblk_slab):
+        return self._grow("_gpanels", (nblk_slab + 1) * self.grad_tiles * 2048)
+
+    def _held_bytes(self):
+        return sum(b.numel() * b.element_size() for b in (self._fpanels, self._gpanels, self._masks) if b is not None)
+
+    def plan(self, R, S):
+        """(rays per chunk, rays per slab): a chunk's F panels + masks and one slab's G panels fit the budget; both are multiples
+        of 32 rays (block-aligned for every S) unless they cover the whole ray set"""
+        blk_f = self.fwd_tiles * 2048 + self.mask_u16 * 2
+        blk_g = self.grad_tiles * 2048
+        nb = lambda rays: (rays * S + 31) // 32 + 1
+        slab = min(R, max(32, self.SLAB_BLOCKS * 32 // S // 32 * 32))
+        need_all = nb(R) * blk_f + nb(slab) * blk_g
+        holds_all = (self._fpanels is not None and self._fpanels.numel() >= nb(R) * self.fwd_tiles * 2048
+                     and self._gpanels is not None and self._gpanels.numel() >= nb(slab) * blk_g)
+        if need_all <= self.PANEL_BYTES_BUDGET and holds_all:
+            return R, slab             # the buffers at hand already hold the whole ray set (no driver query on the hot path:
+                                       # hipMemGetInfo synchronises with the device)
+        key = (R, S, self.PANEL_BYTES_BUDGET, self.SLAB_BLOCKS)
+        if getattr(self, "_plan_key", None) == key:
+            return self._plan_val
+        # 80 % of what is free once the current buffers are given back (they are released before larger ones are allocated)
+        budget = max(min(self.PANEL_BYTES_BUDGET, (torch.cuda.mem_get_info(self.device)[0] + self._held_bytes()) * 8 // 10), 1 << 26)
+        if need_all <= budget:
+            chunk = R
+        else:
+            if nb(slab) * (blk_f + blk_g) > budget:          # not even one slab with its own F panels: shrink the slab
+                slab = max(32, (budget // (blk_f + blk_g) - 1) * 32 // S // 32 * 32)
+            chunk = max(slab, ((budget - nb(slab) * blk_g) // blk_f - 1) * 32 // S // 32 * 32)
+            chunk, slab = min(chunk, R), min(slab, R)
+        self._plan_key, self._plan_val = key, (chunk, slab)
+        return self._plan_val
 
     def rays_per_chunk(self, R, S):
-        """how many rays' operand panels fit the budget (see PANEL_BYTES_BUDGET)"""
-        need_all = ((R * S + 31) // 32 + 1) * self.ptiles * 2048
-        if self._panels is not None and self._panels.numel() >= need_all:
-            return R                   # the buffer at hand already holds the whole ray set (no driver query on the hot path:
-                                       # hipMemGetInfo synchronises with the device)
-        key = (R, S, self.PANEL_BYTES_BUDGET)
-        if getattr(self, "_chunk_key", None) == key and self._panels is not None:
-            return self._chunk_val
-        have = self._panels.numel() if self._panels is not None else 0
-        # 70 % of what is free once the current buffer is given back (it is released before a larger one is allocated)
-        budget = max(min(self.PANEL_BYTES_BUDGET, (torch.cuda.mem_get_info(self.device)[0] + have) * 7 // 10), 1 << 28)
-        max_blocks = max(1, budget // (self.ptiles * 2048) - 1)
-        self._chunk_key, self._chunk_val = key, max(1, min(R, int(max_blocks * 32 // S) - 1))
-        return self._chunk_val
+        return self.plan(R, S)[0]
 
     # ------------------------------------------------------------------ forward launches
     def sdf_rays(self, pk: Packed, rays_o, rays_d, z, sdf_out=None, slot=None, ld_out=0):
@@ -221,7 +252,7 @@ class Engine:
                    torch.empty(R, S, 6, device=self.device, dtype=torch.float32))
         sdf, nrm, rgb = out
         npts = (r1 - r0) * S
-        panels, masks = self._bufs((npts + 31) // 32)
+        panels, masks = self._bufs_f((npts + 31) // 32)
         esz = 4
         with Engine._Timed("avc_render_points_fwd_train", npts):
             L.check(self.lib.avc_render_points_fwd_train(
@@ -264,47 +295,55 @@ class Engine:
 
     # ------------------------------------------------------------------ backward of the point MLP
     def points_bwd(self, pk: Packed, rays_o, rays_d, z, sample_dist, d_sdf, d_n, d_rgb, rgb, panels_valid=False):
-        """returns the flat dense gradient [nparam] (fp32).  `rgb` = the forward's colours.  panels_valid: the engine buffers
-        still hold the operand panels of exactly this ray set (single chunk, nothing rendered since) -- otherwise the
-        training forward is re-run per chunk."""
+        """returns the flat dense gradient [nparam] (fp32).  `rgb` = the forward's colours.  panels_valid: the F region still
+        holds the forward-type operand panels of exactly this ray set (one chunk, nothing rendered since) -- otherwise the
+        training forward is re-run per chunk.  The backward itself walks every chunk in slabs: backward kernel (writes the
+        slab's gradient-type panels) + weight-gradient kernel (contracts both regions over the slab)."""
         lay = self.dl.lay
         R, S = z.shape
-        rays_per_chunk = self.rays_per_chunk(R, S)
+        rays_per_chunk, rays_per_slab = self.plan(R, S)
         if rays_per_chunk < R:
             panels_valid = False
         gout = torch.zeros(lay.gout_size, device=self.device, dtype=torch.float32)
         gbias = torch.zeros(max(lay.gbias_size, 1), device=self.device, dtype=torch.float32)
-        nsplit = self.WG_NSPLIT
         if self._partials is None:
-            self._partials = torch.empty(nsplit, lay.gout_size, device=self.device, dtype=torch.float32)
-            self._bpartials = torch.empty(nsplit, max(lay.gbias_size, 1), device=self.device, dtype=torch.float32)
+            self._partials = torch.empty(256, lay.gout_size, device=self.device, dtype=torch.float32)
+            self._bpartials = torch.empty(256, max(lay.gbias_size, 1), device=self.device, dtype=torch.float32)
         st = L.stream()
         esz = 4
         scratch_out = None
-        for r0 in range(0, R, rays_per_chunk):
-            r1 = min(R, r0 + rays_per_chunk)
-            npts = (r1 - r0) * S
-            nblk = (npts + 31) // 32
+        for c0 in range(0, R, rays_per_chunk):
+            c1 = min(R, c0 + rays_per_chunk)
             if not panels_valid:
                 if scratch_out is None:   # outputs of the re-run are not needed (identical to the first pass)
                     scratch_out = (torch.empty(R, S, device=self.device), torch.empty(R, S, 3, device=self.device),
                                    torch.empty(R, S, 6, device=self.device))
-                self.points_fwd_train(pk, rays_o, rays_d, z, sample_dist, r0, r1, out=scratch_out)
-            panels, masks = self._bufs(nblk)
-            with Engine._Timed("avc_render_points_bwd", npts):
-                L.check(self.lib.avc_render_points_bwd(
-                    self.net, None, rays_o.data_ptr() + r0 * 3 * esz, rays_d.data_ptr() + r0 * 3 * esz,
-                    z.data_ptr() + r0 * z.stride(0) * esz, S, z.stride(0), float(sample_dist), npts, L.ptr(pk.w_bf16), L.ptr(pk.tab),
-                    self.dl.offsets, d_sdf.data_ptr() + r0 * S * esz, d_n.data_ptr() + r0 * S * 3 * esz,
-                    d_rgb.data_ptr() + r0 * S * 6 * esz, rgb.data_ptr() + r0 * S * 6 * esz, L.ptr(panels), L.ptr(masks),
-                    self.MAX_BWD_WAVES, st), "avc_render_points_bwd")
-            ns = max(1, min(nblk, nsplit))
-            with Engine._Timed("avc_weight_grad(all pairs)", npts):
-                L.check(self.lib.avc_weight_grad_all(L.ptr(panels), self.ptiles, len(lay.pairs), self._pairs_host.ctypes.data,
-                                                     nblk, L.ptr(self._partials), L.ptr(self._bpartials), ns,
-                                                     self._partials.stride(0), self._bpartials.stride(0), st), "avc_weight_grad_all")
-                gout += self._partials[:ns].sum(0)
-                gbias += self._bpartials[:ns].sum(0)
+                self.points_fwd_train(pk, rays_o, rays_d, z, sample_dist, c0, c1, out=scratch_out)
+            fpanels, masks = self._bufs_f(((c1 - c0) * S + 31) // 32)
+            for s0 in range(c0, c1, rays_per_slab):
+                s1 = min(c1, s0 + rays_per_slab)
+                npts = (s1 - s0) * S
+                nblk = (npts + 31) // 32
+                assert ((s0 - c0) * S) % 32 == 0, "slabs start on a 32-point block of their chunk"
+                fblk0 = (s0 - c0) * S // 32          # the slab's first block in the chunk's F region
+                fptr = fpanels.data_ptr() + fblk0 * self.fwd_tiles * 2048
+                mptr = masks.data_ptr() + fblk0 * self.mask_u16 * 2
+                gpanels = self._bufs_g(nblk)
+                with Engine._Timed("avc_render_points_bwd", npts):
+                    L.check(self.lib.avc_render_points_bwd(
+                        self.net, None, rays_o.data_ptr() + s0 * 3 * esz, rays_d.data_ptr() + s0 * 3 * esz,
+                        z.data_ptr() + s0 * z.stride(0) * esz, S, z.stride(0), float(sample_dist), npts, L.ptr(pk.w_bf16), L.ptr(pk.tab),
+                        self.dl.offsets, d_sdf.data_ptr() + s0 * S * esz, d_n.data_ptr() + s0 * S * 3 * esz,
+                        d_rgb.data_ptr() + s0 * S * 6 * esz, rgb.data_ptr() + s0 * S * 6 * esz, fptr, L.ptr(gpanels), mptr,
+                        self.MAX_BWD_WAVES, st), "avc_render_points_bwd")
+                ns = max(1, min(256, nblk // self.WG_BLOCKS_PER_SPLIT, nblk))
+                with Engine._Timed("avc_weight_grad(all pairs)", npts):
+                    L.check(self.lib.avc_weight_grad_all(fptr, self.fwd_tiles, L.ptr(gpanels), self.grad_tiles, len(lay.pairs),
+                                                         self._pairs_host.ctypes.data, nblk, L.ptr(self._partials),
+                                                         L.ptr(self._bpartials), ns, self._partials.stride(0),
+                                                         self._bpartials.stride(0), st), "avc_weight_grad_all")
+                    gout += self._partials[:ns].sum(0)
+                    gbias += self._bpartials[:ns].sum(0)
         self._panel_owner = None
         grad = torch.zeros(lay.nparam, device=self.device, dtype=torch.float32)
         grad.index_add_(0, self.dl.un_tgt, gout[self.dl.un_src] * self.dl.un_scale)
@@ -327,7 +366,7 @@ class RenderCoreFn(torch.autograd.Function):
         R, S = z_vals.shape
         needs_grad = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])   # (grad mode itself is off inside forward)
         ctx.panel_token = None
-        if needs_grad and eng.rays_per_chunk(R, S) >= R:
+        if needs_grad and eng.plan(R, S)[0] >= R:
             # the whole ray set's operand panels fit: the forward runs once and leaves them for the backward pass
             sdf, nrm, rgb = eng.points_fwd_train(pk, rays_o, rays_d, z_vals, sample_dist)
             ctx.panel_token = eng._panel_owner = object()

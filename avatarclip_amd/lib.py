@@ -15,7 +15,6 @@ P = c_void_p
 _SIGS = {
     "avc_version": (c_int, []),
     "avc_num_offsets": (c_int, []),
-    "avc_bwd_panel_tiles": (c_int, [c_int]),
     "avc_sdf_forward": (c_int, [c_int, P, P, P, P, c_int, c_int, c_long, P, P, P, P, P, c_int, P]),
     "avc_upsample_step": (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, P, P, P, P, P]),
     "avc_render_points_fwd": (c_int, [c_int, P, P, P, P, c_int, c_int, c_float, c_long, P, P, P, P, P, P, c_long, P, P]),
@@ -24,9 +23,10 @@ _SIGS = {
     "avc_composite_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, P, c_float, c_float, P, c_int, P, P, P, P, P, P, P,
                                   P, P, P]),
     "avc_render_points_fwd_train": (c_int, [c_int, P, P, P, P, c_int, c_int, c_float, c_long, P, P, P, P, P, P, c_long, P, P, P]),
-    "avc_panel_tiles": (c_int, [c_int]),
+    "avc_fwd_panel_tiles": (c_int, [c_int]),
+    "avc_grad_panel_tiles": (c_int, [c_int]),
     "avc_mask_u16_per_block": (c_int, [c_int]),
-    "avc_render_points_bwd": (c_int, [c_int, P, P, P, P, c_int, c_int, c_float, c_long, P, P, P, P, P, P, P, P, P, c_long, P]),
+    "avc_render_points_bwd": (c_int, [c_int, P, P, P, P, c_int, c_int, c_float, c_long, P, P, P, P, P, P, P, P, P, P, c_long, P]),
     "avc_mc_classify": (c_int, [P, c_int, c_int, c_int, c_float, P, P, P, P]),
     "avc_mc_emit": (c_int, [P, c_int, c_int, c_int, c_float, P, P, P, P, P, P, P, P, P]),
     "avc_text_attention_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
@@ -37,7 +37,7 @@ _SIGS = {
     "avc_vit_attention_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "avc_probe_mfma": (c_int, [P, P, P, P, P, P, P]),
     "avc_rasterize_faces": (c_int, [P, P, c_int, c_int, c_float, c_float, P, P]),
-    "avc_weight_grad_all": (c_int, [P, c_int, c_int, P, c_long, P, P, c_int, c_int, c_int, P]),
+    "avc_weight_grad_all": (c_int, [P, c_int, P, c_int, c_int, P, c_long, P, P, c_int, c_int, c_int, P]),
 }
 _OPTIONAL = {}
 

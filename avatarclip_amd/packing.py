@@ -178,7 +178,7 @@ class Layout:
     scale32: np.ndarray
     offsets: np.ndarray
     panel: Dict[str, int]
-    pairs: List[Tuple[int, int, int, int, int, int, int, int]]   # (pa, ta, pb, tb, out_off, bias_off, type_a, type_b); type 0 = f16 tile, 1 = bf16 tile
+    pairs: List[Tuple[int, int, int, int, int, int, int, int]]   # (pa, ta, pb, tb, out_off, bias_off, type_a, type_b); pa / pb = GLOBAL tile ids (see build_layout), type 0 = F region / f16 tile, 1 = G region / bf16 tile
     gout_size: int
     gbias_size: int
     un_src: np.ndarray
@@ -322,19 +322,25 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
     table("OFF_CBH", bias_tab("col.bh", 6, 1))
     offsets[OFF["OFF_TAB_END"]] = cur32[0]
 
-    # ---------------- panel layout (mirror of PanelLayout in csrc/avc_mlp.h)
+    # ---------------- panel layout (mirror of PanelLayout in csrc/avc_mlp.h): two regions with their own block stride.
+    # P[name] is a GLOBAL tile id: F-region tiles (forward-type operands, f16, written by the forward kernel for the whole ray set)
+    # are numbered 0 .. FTILES-1 in region order, G-region tiles (gradient-type operands, bf16, written by the backward kernel for
+    # one slab at a time) FTILES .. FTILES+GTILES-1; the region-local index the kernels use is id (F) resp. id - FTILES (G).
     P = {}
     c = 0
-    # forward-type operands are written by the forward kernel as f16 tiles, gradient-type operands by the backward kernel as bf16
-    F16_PANELS = ("H0", "H1", "HM", "HS", "GA1", "GAM", "GAS", "FEAT", "XN", "R1", "R2")
+    F_ORDER = [("H1", HT), ("HM", NMID * HT), ("HS", ST), ("H0", 2), ("GA1", HT), ("GAM", NMID * HT), ("GAS", ST), ("FEAT", HT),
+               ("XN", 1), ("R1", HT), ("R2", NCMID * HT)]
+    G_ORDER = [("GBH1", HT), ("GBHM", NMID * HT), ("GBHS", ST), ("GB0", 2), ("AB1", HT), ("ABM", NMID * HT), ("ABS", ST),
+               ("DFEAT", HT), ("SDF", 1), ("ONE", 1), ("D1", HT), ("D2", NCMID * HT), ("DO", 1)]
     tile_type = []
-    for name, nt in [("H1", HT), ("HM", NMID * HT), ("HS", ST), ("H0", 2), ("GBH1", HT),
-                     ("GBHM", NMID * HT), ("GBHS", ST), ("GB0", 2), ("GA1", HT), ("GAM", NMID * HT), ("GAS", ST), ("AB1", HT),
-                     ("ABM", NMID * HT), ("ABS", ST), ("DFEAT", HT), ("SDF", 1), ("ONE", 1), ("FEAT", HT), ("XN", 1),
-                     ("R1", HT), ("R2", NCMID * HT), ("D1", HT), ("D2", NCMID * HT), ("DO", 1)]:
-        P[name] = c
-        c += nt
-        tile_type += [0 if name in F16_PANELS else 1] * nt
+    for region, order in ((0, F_ORDER), (1, G_ORDER)):
+        for name, nt in order:
+            P[name] = c
+            c += nt
+            tile_type += [region] * nt
+        if region == 0:
+            P["FTILES"] = c
+    P["GTILES"] = c - P["FTILES"]
     P["TILES"] = c
 
     def panel_type(tile):
@@ -443,3 +449,13 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
 
 def layout_for(spec: NetSpec) -> Layout:
     return build_layout(spec.H, spec.NMID, spec.NCMID)
+
+
+def region_local_pairs(lay: Layout) -> np.ndarray:
+    """the pair table the C ABI takes (avc_weight_grad_all): tile indices local to their region (F: id, G: id - FTILES)"""
+    ft = lay.panel["FTILES"]
+    out = np.asarray(lay.pairs, dtype=np.int32).reshape(-1, 8).copy()
+    out[:, 0] -= np.where(out[:, 6] == 1, ft, 0)
+    out[:, 2] -= np.where(out[:, 7] == 1, ft, 0)
+    assert (out[:, 0] >= 0).all() and (out[:, 2] >= 0).all()
+    return np.ascontiguousarray(out)

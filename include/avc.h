@@ -73,40 +73,47 @@ int avc_composite_bwd(const float* sdf, const float* normal, const float* rgb, c
 
 /* The differentiable forward of render_core (renderer.py:221-232, once per iteration as in the reference): the same outputs
  * as avc_render_points_fwd, plus everything the backward pass and the weight-gradient products need from the forward pass,
- * written to the OPERAND PANELS of each 32-point block: avc_panel_tiles(net) tiles of 2 KiB per block, each tile = the two
- * 16-bit B-operand fragments [k-step][lane = point + 32 half][8 features] of 32 features x 32 points (f16 for what this
- * kernel writes: PE values, h_l, g_a,l, feature vector, [x,n], r1, r2), and the ReLU masks of r1 / r2
- * (avc_mask_u16_per_block(net) x 16 bits per block).  Both buffers need (nblk + 1) blocks, nblk = ceil(npts / 32): the
- * last block is a sink for wavefronts past the end. */
-int avc_panel_tiles(int net);
+ * written to the F REGION of the OPERAND PANELS: per 32-point block avc_fwd_panel_tiles(net) tiles of 2 KiB, each tile = the
+ * two 16-bit B-operand fragments [k-step][lane = point + 32 half][8 features] of 32 features x 32 points (f16: PE values,
+ * h_l, g_a,l, feature vector, [x,n], r1, r2), and the ReLU masks of r1 / r2 (avc_mask_u16_per_block(net) x 16 bits per
+ * block).  Both buffers need (nblk + 1) blocks, nblk = ceil(npts / 32): the last block is a sink for wavefronts past the end.
+ * The gradient-type operands (bf16: gbar_h, abar, delta, ybar) live in a separate G REGION of avc_grad_panel_tiles(net) tiles
+ * per block that only ever holds one SLAB of blocks (see avc_render_points_bwd). */
+int avc_fwd_panel_tiles(int net);
+int avc_grad_panel_tiles(int net);
 int avc_mask_u16_per_block(int net);
 int avc_render_points_fwd_train(int net, const float* pts, const float* rays_o, const float* rays_d, const float* z,
                                 int S, int ldz, float sample_dist, long npts, const void* wf16, const float* tab,
                                 const int* offs /* host */, float* sdf_out, float* normal_out, float* rgb_out,
-                                long max_waves, void* panels, void* masks, void* stream);
+                                long max_waves, void* fpanels, void* masks, void* stream);
 
 /* Backward of avc_render_points_fwd_train wrt every dense weight (autograd incl. the double backward of
- * SDFNetwork.gradient, fields.py:96-107; main.py:537).  Recomputes nothing of the forward: reads h_l, g_a,l, the masks and
- * the colours (rgb_fwd = the forward's rgb_out) back, runs the colour backward, the second-order sweep and the reverse sweep
- * (bf16 operands) and adds the gradient-type operand tiles (gbar_h, abar, delta, ybar; bf16) to the same panels;
- * avc_weight_grad_all then contracts the panels over the points.  max_waves bounds the resident grid (persistent
+ * SDFNetwork.gradient, fields.py:96-107; main.py:537) for one SLAB of npts points (a block-aligned sub-range of the forward's
+ * points: the ray / z / gradient pointers and fpanels / masks point at the slab's first ray resp. first block).  Recomputes
+ * nothing of the forward: reads h_l, g_a,l (fpanels), the masks and the colours (rgb_fwd = the forward's rgb_out) back, runs
+ * the colour backward, the second-order sweep and the reverse sweep (bf16 operands) and writes the gradient-type operand
+ * tiles of the slab to gpanels ((nblk + 1) blocks of avc_grad_panel_tiles(net) tiles, block 0 = the slab's first block);
+ * avc_weight_grad_all then contracts both regions over the slab's points.  max_waves bounds the resident grid (persistent
  * workgroups of 8 wavefronts). */
-int avc_bwd_panel_tiles(int net);   /* == avc_panel_tiles */
 int avc_render_points_bwd(int net, const float* pts, const float* rays_o, const float* rays_d, const float* z,
                           int S, int ldz, float sample_dist, long npts, const void* wbf16, const float* tab,
                           const int* offs /* host */, const float* d_sdf, const float* d_normal, const float* d_rgb,
-                          const float* rgb_fwd, void* panels, const void* masks, long max_waves, void* stream);
+                          const float* rgb_fwd, const void* fpanels, void* gpanels, const void* masks, long max_waves,
+                          void* stream);
 
-/* Every weight-gradient product of one backward pass in one launch.  pairs (host) = npairs x {pa, ta, pb, tb, out_off,
- * bias_off, type_a, type_b}: pair i contracts A tiles pa .. pa+ta-1 (ta <= 8) with B tiles pb .. pb+tb-1 (tb <= 9) over the
- * points of `nblk` blocks; type = 0 (f16 tile) | 1 (bf16 tile).  The fragment-layout tiles are transposed to
- * feature-major on the matrix core as they are loaded (two MFMAs against a 0/1 selection fragment per tile) and contracted
- * in bf16 with fp32 accumulation.  partial[split][out_off + ((ta_i * tb + tb_j) * 64 + lane) * 16 + r] = element
+/* Every weight-gradient product of one slab in one launch.  pairs (host) = npairs x {pa, ta, pb, tb, out_off, bias_off,
+ * type_a, type_b}: pair i contracts A tiles pa .. pa+ta-1 with B tiles pb .. pb+tb-1 (1 <= ta <= 8, 1 <= tb <= 9, or the merged
+ * last-layer product ta = tb = 9) over the points of `nblk` blocks; type selects the operand's region and element type: 0 = F
+ * region (fpanels, ftiles tiles per block, f16), 1 = G region (gpanels, gtiles per block, bf16), tile indices are
+ * region-local.  The tiles are copied to LDS by global->LDS DMA in a chunk order that lets gfx950's LDS transpose read
+ * (ds_read_b64_tr_b16) hand every lane its feature-major fragment, f16 operands are converted to bf16 after the read, and the
+ * products accumulate in fp32.  partial[split][out_off + ((ta_i * tb + tb_j) * 64 + lane) * 16 + r] = element
  * dW[32 ta_i + (r&3)+8(r>>2)+4h][32 tb_j + n] of lane (n,h); bias_partial[split][bias_off + 32 ta_i + n] = sum_points
  * A[:, 32 ta_i + n] (bias_off < 0: none).  nsplit = split-K factor (grid x); split s writes its slab at
  * partial + s*out_stride (bias_partial + s*bias_stride), floats; the caller sums the slabs (no atomics). */
-int avc_weight_grad_all(const void* panels, int ptiles, int npairs, const int* pairs /* host */, long nblk, float* partial,
-                        float* bias_partial, int nsplit, int out_stride, int bias_stride, void* stream);
+int avc_weight_grad_all(const void* fpanels, int ftiles, const void* gpanels, int gtiles, int npairs,
+                        const int* pairs /* host */, long nblk, float* partial, float* bias_partial, int nsplit,
+                        int out_stride, int bias_stride, void* stream);
 
 /* ---- mesh extraction (Runner.validate_mesh, main.py:850-919; renderer.py:10-36; mcubes.marching_cubes) ----
  * Marching cubes over u[nx][ny][nz] (row-major, the reference's extract_fields layout) at iso level `iso`, inside = u > iso,

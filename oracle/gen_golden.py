@@ -12,7 +12,7 @@ Fixtures:
   neus_small.npz   shipped small checkpoint (real weights), camera 58 of zero_beta_standpose_render,
                    256 rays, perturb 0: per-step up-sampling intermediates, render outputs, parameter grads
   neus_full.npz    full-size nets (confs/examples/*.conf), torch.manual_seed(0) geometric init + perturbed
-                   weights, 96 rays, injected jitter
+                   weights, 512 rays (24 x 24 view, first 512), injected jitter
   sampling_kat.npz known-answer vectors for sample_pdf / up_sample on seeded inputs
   rays_cam.npz     ray generation / near-far / camera helpers
 """
@@ -213,14 +213,17 @@ def main():
         var.variance.fill_(0.45)
     eye = np.array([0.6, 0.4, 1.3], dtype=np.float32)
     pose = torch.from_numpy(ut_fns["lookat"](eye, np.zeros(3, np.float32), np.array([0, 1, 0]))).float()
-    fake_self.W = fake_self.H = 24
-    f24 = 0.5 * 24 / np.tan(np.pi / 6)
-    fake_self.K = torch.from_numpy(np.array([[f24, 0, 12.0], [0, f24, 12.0], [0, 0, 1]]))
+    # 512 rays (round 2 had 96: its 6144 points left the colour-branch gradients of the bf16 path at 1.7-1.9 %, ReLU-flip sampling
+    # noise of a small point set; VERDICT r2 item 4b asks for >= 512 rays so that SURVEY 8d's 1e-2 gate can be asserted)
+    NF = 512
+    fake_self.W = fake_self.H = 48
+    f48 = 0.5 * 48 / np.tan(np.pi / 6)
+    fake_self.K = torch.from_numpy(np.array([[f48, 0, 24.0], [0, f48, 24.0], [0, 0, 1]]))
     o, v = ds_fns["gen_rays_pose"](fake_self, pose, 2)
     ro, rd = o.reshape(-1, 3).float().contiguous(), v.reshape(-1, 3).float().contiguous()
     nearf, farf = ds_fns["near_far_from_sphere"](fake_self, ro, rd)
-    ro, rd, nearf, farf = ro[:96], rd[:96], nearf[:96], farf[:96]
-    jitter = torch.rand(96, 1, generator=torch.Generator().manual_seed(3))
+    ro, rd, nearf, farf = ro[:NF], rd[:NF], nearf[:NF], farf[:NF]
+    jitter = torch.rand(NF, 1, generator=torch.Generator().manual_seed(3))
     rec = run_case(R, sdf, col, var, 32, 32, 4, ro, rd, nearf, farf, jitter, None, 0.3, seed=4)
     rec.update(sd_np(sdf.state_dict(), "sdf."))
     rec.update(sd_np(col.state_dict(), "col."))

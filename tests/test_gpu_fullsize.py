@@ -74,6 +74,48 @@ def test_fullsize_sampling_and_compositing_properties(spp):
 
 
 @gpu
+def test_fullsize_one_launch_render_matches_oracle_on_256_rays():
+    """512 x 512 rays x 64 spp through the TRAINING path (one forward launch over the whole view: operand-panel offsets far
+    beyond 2^32 bytes), then 256 of its rays -- the first and the last, the rays whose panel blocks straddle every multiple of
+    4 GiB of the forward panel region, and random ones -- against the CPU oracle on the kernel's own depths
+    (renderer.py:195-300, fields.py:72-107,154-185)."""
+    dev = torch.device("cuda")
+    sdf, col, var, ren = _full_renderer(dev)
+    ro, rd, near, far = _view(512, dev)
+    R = ro.shape[0]
+    eng = ren.engine
+    pk = eng.pack(ren.flat_params())
+    with torch.no_grad():
+        z = ren.sample_z(pk, ro, rd, near, far, 1.0, jitter=torch.rand(R, 1, device=dev, generator=torch.Generator(device=dev).manual_seed(9)))
+    bg = torch.tensor([[0.1, 0.6, 0.3]], device=dev)
+    out = ren.render(ro, rd, near, far, background_rgb=bg, cos_anneal_ratio=0.7, z_vals=z)     # grad mode on: avc_render_points_fwd_train
+    assert out["color_fine"].requires_grad
+    assert eng.rays_per_chunk(R, 64) >= R, "the whole view is expected to be one launch on a 288 GB device"
+    torch.cuda.synchronize()
+    fwd_bytes_per_block = eng.fwd_tiles * 2048
+    pick = {0, 1, R - 2, R - 1}
+    k = 1
+    while k * (1 << 32) < (R * 64 // 32) * fwd_bytes_per_block:
+        blk = k * (1 << 32) // fwd_bytes_per_block
+        for b in (blk - 1, blk, blk + 1):
+            pick.add(min(R - 1, max(0, b * 32 // 64)))
+        k += 1
+    rs = np.random.RandomState(3)
+    while len(pick) < 256:
+        pick.add(int(rs.randint(0, R)))
+    idx = torch.tensor(sorted(pick)[:256], dtype=torch.long)
+    sd_s = {k_: v.detach().cpu() for k_, v in sdf.named_parameters()}
+    sd_c = {k_: v.detach().cpu() for k_, v in col.named_parameters()}
+    di = idx.to(dev)
+    ref = O.render(sd_s, sd_c, var.variance.detach().cpu(), ro[di].cpu(), rd[di].cpu(), near[di].cpu(), far[di].cpu(),
+                   background_rgb=bg.cpu(), cos_anneal_ratio=0.7, z_vals=z[di].cpu())
+    for key, tol in (("color_fine", 5e-3), ("extra_color_fine", 5e-3), ("weights", 5e-3)):
+        e = (out[key].detach()[di].cpu() - ref[key].detach()).abs()
+        print(key, "max", e.max().item(), "mean", e.mean().item(), "rays", len(idx))
+        assert e.max() < tol, key
+
+
+@gpu
 def test_fullsize_gradient_linearity_and_chunk_invariance():
     from avatarclip_amd.engine import Engine
     dev = torch.device("cuda")

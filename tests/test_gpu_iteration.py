@@ -122,6 +122,11 @@ def _run_parity(res, spp, iters, small, silhouettes=False, rel_tol=2e-2, cos_tol
             R = int(a.dataset.W // a.full_frame_resolution_level) ** 2
         jit["t"] = torch.rand(R, 1, generator=torch.Generator().manual_seed(100 + i))
         np.random.seed(4321 + i)
+        w_before = [p.detach().cpu().clone() for p in a.params_to_train]
+        wo_before = [p.detach().clone() for p in st.params()]
+        for pa, pb in zip(w_before, wo_before):       # the two legs start every iteration from (nearly) the same weights
+            assert (pa - pb).abs().max() <= 2.5 * a.learning_rate
+        lr_used = a.optimizer.param_groups[0]["lr"]
         la = a.train_clip_iteration(i, camera=cams[i])
         grads_a = [p.grad.detach().cpu().clone() for p in a.params_to_train]
         a.update_learning_rate()
@@ -139,9 +144,25 @@ def _run_parity(res, spp, iters, small, silhouettes=False, rel_tol=2e-2, cos_tol
         assert abs(a.last_stats["cosine"].item() - ob["cosine"].item()) < 1e-3
         w = _check_grads(names, grads_a, ob["grads"], sdf_last_bias, rel_tol, cos_tol, bias_tol)
         worst = max(worst, w)
-        # after the Adam step the two weight sets stay together (a sign-flipped or mis-scaled gradient would show here at once)
-        for pa, pb in zip(a.params_to_train, st.params()):
-            assert (pa.detach().cpu() - pb.detach()).abs().max() < 3 * a.optimizer.param_groups[0]["lr"] + 1e-6
+        # after the Adam step: both legs must have MOVED every significant weight the same way by (nearly) the same amount.
+        # Adam's update is ~lr * sign(g) on the first step, so a bound of a few lr on |w_hip - w_oracle| cannot fail (a sign-flipped
+        # gradient gives 2 lr); instead, on the entries whose gradient is above 1e-2 of the tensor's largest one (about half of all
+        # entries): the two displacements share their sign and agree to 0.2 lr, each on >= 99 % of those entries.  (With the cut
+        # at 1e-3 an unbiased per-entry error of 0.7 % of the tensor's RMS -- what bf16 operands give -- already flips 2 % of the
+        # entries next to the cut in the second iteration; at 1e-2 errors up to 1.5 % pass and a flipped sign scores 0 %.)
+        agree_min, close_min = 1.0, 1.0
+        for n, w0, wo0, pa, pb, gb in zip(names, w_before, wo_before, a.params_to_train, st.params(), ob["grads"]):
+            sel = gb.abs() > 1e-2 * gb.abs().max()
+            if gb.abs().max() < 1e-7 or sel.sum() == 0:
+                continue
+            da, db = (pa.detach().cpu() - w0)[sel], (pb.detach() - wo0)[sel]
+            agree = (torch.sign(da) == torch.sign(db)).float().mean().item()
+            close = ((da - db).abs() <= 0.2 * lr_used + 1e-9).float().mean().item()
+            agree_min, close_min = min(agree_min, agree), min(close_min, close)
+            assert db.abs().max() > 0.5 * lr_used, (n, "the oracle leg did not step")
+            assert agree >= 0.99 and close >= 0.99, (n, agree, close, int(sel.sum()))
+        print("iter %d  Adam displacement: sign agreement >= %.4f, |w_hip - w_oracle| <= 0.2 lr on >= %.4f of the significant entries"
+              % (i, agree_min, close_min))
     print("worst per-tensor relative gradient error", worst)
     return worst
 

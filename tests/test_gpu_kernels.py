@@ -243,7 +243,9 @@ def test_parameter_gradients_match_golden(name):
             cos = torch.nn.functional.cosine_similarity(g.reshape(1, -1).double(), ref.reshape(1, -1).double()).item()
             print("  %-22s rel %.3e cos %.5f |ref| %.3e" % (pfx + n_, re, cos, ref.norm().item()))
             worst = max(worst, re)
-            assert re < 2e-2 and cos > 0.9995, (pfx + n_, re, cos)   # parameter gradients <= 1e-2..2e-2 (bf16 operands); measured <= 1.7e-2
+            # parameter gradients <= 1e-2 (bf16 operands).  Full-size nets: the 512-ray fixture (32 768 points) is asserted at
+            # that gate; the shipped small checkpoint's 256 rays keep 1.5e-2 (measured 1.1e-2 on its worst tensor)
+            assert re < (1e-2 if name == "neus_full.npz" else 1.5e-2) and cos > 0.9995, (pfx + n_, re, cos)
 
 
 @gpu

@@ -81,11 +81,15 @@ __device__ __forceinline__ void pin4(V& a, V& b, V& c, V& d) { asm("" : "+v"(a),
 #ifndef AVC_VALU_PER_MFMA
 #define AVC_VALU_PER_MFMA 10
 #endif
+#ifndef AVC_TRANS_PER_MFMA
+#define AVC_TRANS_PER_MFMA 0   // > 0: ask for that many transcendentals right behind every MFMA (they issue under the matrix pipe for free up to ~2 per MFMA: profiles/r02_ubench2.txt), the plain VALU slice after them
+#endif
 template <int KS>
 __device__ __forceinline__ void interleave_mfma_valu() {
 #pragma unroll
   for (int k = 0; k < KS; ++k) {
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // 1 MFMA
+    if (AVC_TRANS_PER_MFMA > 0) __builtin_amdgcn_sched_group_barrier(0x400, AVC_TRANS_PER_MFMA, 0);   // transcendentals
     __builtin_amdgcn_sched_group_barrier(0x002, AVC_VALU_PER_MFMA, 0);   // then a slice of VALU
   }
 }

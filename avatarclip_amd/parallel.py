@@ -13,7 +13,10 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # under a launcher (torch.distributed.run sets RANK and WORLD_SIZE) the process group is created for ONE rank too: the
+    # single-rank job then runs the same broadcast / flat-bucket all-reduce path over RCCL as the 8-rank one
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if (world > 1 or launched) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -24,6 +27,11 @@ def init_from_env(backend=None):
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
+
+
+def is_on():
+    """a process group exists (possibly of one rank): parameters are broadcast and gradients go through the flat bucket"""
+    return dist.is_available() and dist.is_initialized()
 
 
 def rank_world():
@@ -72,9 +80,10 @@ class GradBucket:
             elif g.data_ptr() != v.data_ptr():   # autograd replaced the tensor: bring it home (first step only)
                 v.copy_(g)
             p.grad = v
-        if world > 1:
+        if is_on():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.div_(world)
+            if world > 1:
+                self.flat.div_(world)
 
 
 def allreduce_grads(params, world=None):

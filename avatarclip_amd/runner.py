@@ -134,10 +134,10 @@ class Runner:
         params_to_train = list(self.sdf_network.parameters()) + list(self.deviation_network.parameters()) + \
             list(self.color_network.parameters())
         self.params_to_train = params_to_train
-        if self.world > 1:
+        if parallel.is_on():
             parallel.broadcast_params(params_to_train)
             self.seed_data_rngs()
-        self.grad_bucket = parallel.GradBucket(params_to_train) if self.world > 1 else None
+        self.grad_bucket = parallel.GradBucket(params_to_train) if parallel.is_on() else None
         self.optimizer = torch.optim.Adam(params_to_train, lr=self.learning_rate)
         self.renderer = NeuSRenderer(self.nerf_outside, self.sdf_network, self.deviation_network, self.color_network,
                                      **self.conf["model.neus_renderer"])

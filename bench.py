@@ -30,20 +30,26 @@ F_SDF_ONLY = 2 * (39 * 256 + 2 * 256 * 256 + 256 * 217 + 256)   # SDF value only
 PEAK_MFMA = 2.5e15   # dense bf16/f16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM = 8.0e12    # HBM3E, MI355X_MICROARCH.md (6.3e12 achievable for a pure copy)
 TILE = 64            # bytes per point of one 32-feature operand tile (2 KiB per 32-point block)
-# The MLP kernels of one training step, each with the roofline that bounds it:
-#   algorithmic FLOPs per point: SURVEY.md 8d; algorithmic bytes per point: the operand tiles a kernel must read once and write once
-#   (full nets: 180 tiles = 11.25 KiB per point in total: 89 written by the forward kernel, 91 by the backward kernel)
+# The MLP kernels of one training step.  SURVEY.md 8d prices the whole MLP path against the dense bf16/f16 MFMA peak (every one of
+# these kernels is a chain of dense contractions), so `frac` is ALWAYS algorithmic FLOPs / time / 2.5 PFLOP/s; what actually
+# limits a kernel of this design is reported beside it (`limited_by`, `hbm_frac_counter` = PMC bytes / time / 8 TB/s,
+# `traffic_ratio` = PMC bytes / algorithmic bytes).  Algorithmic bytes per point = the operand tiles a kernel must read once and
+# write once (full nets: 180 tiles = 11.25 KiB per point in total: 89 written by the forward kernel, 91 by the backward kernel).
 KERNEL_ROOFLINES = {
-    "avc_render_points_fwd_train": dict(kernel="mlp_render_kernel<train>", bound="mfma", flop_per_point=F_PT, bytes_per_point=89 * TILE + 76,
-                                        note="differentiable forward (F_pt = 1 186 816 FLOP/point) + the forward-type operand tiles; "
-                                             "matrix / vector work of the epilogues bounds it, the tile stores ride along"),
-    "avc_render_points_bwd": dict(kernel="mlp_bwd_kernel", bound="hbm", flop_per_point=F_PT, bytes_per_point=(91 + 62) * TILE + 80,
-                                  note="colour backward + second-order + reverse sweep (F_pt FLOP/point, no forward recompute); HBM-bound: "
-                                       "writes 91 gradient-type tiles, reads h and g_a (62 tiles) -- its own gbar_h / ybar re-reads "
-                                       "(70 tiles) are on top of the algorithmic bytes"),
-    "avc_weight_grad(all pairs)": dict(kernel="weight_grad_all_kernel", bound="hbm", flop_per_point=F_PT, bytes_per_point=180 * TILE,
-                                       note="dW = sum_points A^T B from the operand panels (F_pt FLOP/point, AI = 103 FLOP/B < ridge 312): "
-                                            "HBM-bound by construction; 184 tile reads per block for 180 distinct tiles"),
+    "avc_sdf_forward": dict(kernel="mlp_sdf_kernel", limited_by="engine (MFMA + VALU + LDS issue of the register-resident MLP)", flop_per_point=F_SDF_ONLY,
+                            bytes_per_point=4 + 4 + 1,
+                            note="SDF value at the sampler's points (renderer.py:337-338,187): four f16 GEMM layers + an fp32 dot product, no HBM "
+                                 "traffic to speak of -- the SDF-MLP GEMM north_star names"),
+    "avc_render_points_fwd_train": dict(kernel="mlp_render_kernel<train>", limited_by="engine, with the forward-type tile stores riding along", flop_per_point=F_PT,
+                                        bytes_per_point=89 * TILE + 76,
+                                        note="differentiable forward (F_pt = 1 186 816 FLOP/point) + the 89 forward-type operand tiles"),
+    "avc_render_points_bwd": dict(kernel="mlp_bwd_kernel", limited_by="hbm", flop_per_point=F_PT, bytes_per_point=(91 + 62) * TILE + 80,
+                                  note="colour backward + second-order + reverse sweep (F_pt FLOP/point, no forward recompute): writes 91 "
+                                       "gradient-type tiles, reads h and g_a (62 tiles); its own gbar_h / ybar / second h re-reads (70 tiles) are on "
+                                       "top of the algorithmic bytes"),
+    "avc_weight_grad(all pairs)": dict(kernel="weight_grad_all_kernel", limited_by="hbm", flop_per_point=F_PT, bytes_per_point=180 * TILE,
+                                       note="dW = sum_points A^T B from the operand panels (F_pt FLOP/point): every tile is used by ONE product "
+                                            "pair, so operands streamed from HBM cap the kernel at AI = 103 FLOP/B, below the 312 FLOP/B ridge"),
 }
 
 
@@ -163,6 +169,104 @@ def cpu_baseline(spp, rays=4096, iters=2, max_threads=16):
             "reference_vs_port_table": "profiles/r02_cpu_reference_vs_port.md"}
 
 
+def load_pmc():
+    """HBM traffic per point measured with the PMC counters (separate rocprofv3 --pmc passes of this command, summarised by
+    scripts/pmc_summary.py --json into profiles/): 2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction.  Newest round first."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        with open(path) as fh:
+            return json.load(fh), os.path.relpath(path, ROOT)
+    return {}, None
+
+
+def build_runner(res, spp, small, dev):
+    from avatarclip_amd.runner import Runner
+    # identical initial weights on every rank (train.seed = 0 in the conf + broadcast); the Runner then re-seeds the DATA RNGs
+    # per rank (a different camera view, jitter and light per rank: view-sharded DP, Runner.seed_data_rngs)
+    conf = make_conf(res, spp, small)
+    runner = Runner(None, mode="train_clip", conf=conf, device=dev)
+    runner.init_clip()
+    # the silhouette / colour prior: the SMPL template mesh (reference data/zero_beta_smpl.obj, packed in the test fixture) through
+    # the HIP rasteriser with neural_renderer's conventions -- the same per-iteration work as main.py:360
+    mesh_npz = os.path.join(ROOT, "tests", "golden", "smpl_views.npz")
+    if os.path.exists(mesh_npz):
+        from avatarclip_amd.smpl_prior import MeshPrior
+        z = np.load(mesh_npz)
+        runner.init_smpl(MeshPrior(z["mesh_v"], z["mesh_f"], device=dev))
+    else:
+        runner.init_smpl()
+    runner.update_learning_rate()
+    return runner
+
+
+def timed_steps(runner, steps, warmup, dev, sync_debug=False):
+    """`warmup` untimed + `steps` timed train_clip iterations, bracketed by barrier + synchronize, max over ranks.
+    Returns (seconds, per-kernel {name: [(points, seconds), ..]} from events recorded on the launch stream)."""
+    from avatarclip_amd import parallel
+    from avatarclip_amd.engine import Engine
+
+    def step(i):
+        runner.train_clip_iteration(i)
+        runner.update_learning_rate()
+
+    for i in range(warmup):
+        step(i)
+    Engine.PROFILE = True
+    Engine.prof_events = []
+    parallel.barrier()
+    torch.cuda.synchronize()
+    if sync_debug:
+        torch.cuda.set_sync_debug_mode("warn")
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    if sync_debug:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    parallel.barrier()
+    dt = time.perf_counter() - t0
+    dt = parallel.max_over_ranks(dt, dev)
+    Engine.PROFILE = False
+    per_kernel = {}
+    for name, npts, e0, e1 in Engine.prof_events:
+        per_kernel.setdefault(name, []).append((npts, e0.elapsed_time(e1) * 1e-3))
+    Engine.prof_events = []
+    return dt, per_kernel
+
+
+def kernel_rooflines(per_kernel, steps):
+    """per MLP kernel: frac = algorithmic FLOPs / kernel time / dense MFMA peak, with the HBM view beside it.  One
+    "launch" below = the kernel's launches of ONE step taken together (the backward pair runs once per slab of the view)."""
+    pmc, pmc_path = load_pmc()
+    roofs = {}
+    for name, spec in KERNEL_ROOFLINES.items():
+        if name not in per_kernel:
+            continue
+        recs = per_kernel[name]
+        t_step = float(np.sum([t for _, t in recs])) / steps            # seconds of this kernel per step
+        pts_step = float(np.sum([n for n, _ in recs])) / steps          # points it processes per step
+        flops, nbytes = spec["flop_per_point"] * pts_step, spec["bytes_per_point"] * pts_step
+        tr = pmc.get("kernels", {}).get(spec["kernel"])
+        traffic = tr["bytes_per_point"] * pts_step if tr else None
+        roofs[name] = {
+            "kernel": "%s (%s)" % (spec["kernel"], name), "bound": "mfma", "achieved": flops / t_step / 1e12, "peak": PEAK_MFMA / 1e12,
+            "unit": "TFLOP/s", "frac": flops / t_step / PEAK_MFMA,
+            "limited_by": spec["limited_by"],
+            "traffic": traffic, "traffic_source": ("%s (commit %s, %s)" % (pmc_path, pmc.get("commit"), pmc.get("box"))) if tr else None,
+            "hbm_frac_counter": (traffic / t_step / PEAK_HBM) if tr else None,
+            "hbm_frac_algorithmic": nbytes / t_step / PEAK_HBM,
+            "traffic_ratio": (traffic / nbytes) if tr else None,
+            "ms_per_step": t_step * 1e3, "points_per_step": pts_step, "launches_per_step": len(recs) / steps,
+            "algorithmic_flop_per_point": spec["flop_per_point"], "algorithmic_bytes_per_point": spec["bytes_per_point"],
+            "note": spec["note"]}
+    return roofs
+
+
+def step_flops(res, spp):
+    """algorithmic FLOPs of the MLP work of one step: (S + I (k-1)/k) F_sdf' + (S + I) 3 F_pt per ray"""
+    return res * res * ((spp // 2 + (spp // 2) * 3 // 4) * F_SDF_ONLY + spp * 3 * F_PT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,6 +276,7 @@ def main():
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--small", action="store_true", help="128-wide nets (confs/examples_small)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs legs (BASELINE configs 2 and 3-per-GPU)")
     ap.add_argument("--sync-debug", action="store_true", help="development aid: warn (with a stack) on every host-device synchronisation inside the timed steps")
     args = ap.parse_args()
 
@@ -191,8 +296,6 @@ def main():
         sys.exit(subprocess.call(cmd, env=env))
 
     from avatarclip_amd import parallel
-    from avatarclip_amd.engine import Engine
-    from avatarclip_amd.runner import Runner
     rank, world, local_rank = parallel.init_from_env()
     if world != max(args.gpus, 1):
         sys.exit("bench.py: --gpus %d but WORLD_SIZE = %d (launch with torch.distributed.run --nproc-per-node == --gpus)" % (args.gpus, world))
@@ -200,81 +303,22 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # identical initial weights on every rank (train.seed = 0 in the conf + broadcast); the Runner then re-seeds the DATA RNGs
-    # per rank (a different camera view, jitter and light per rank: view-sharded DP, Runner.seed_data_rngs)
-    conf = make_conf(args.res, args.spp, args.small)
-    runner = Runner(None, mode="train_clip", conf=conf, device=dev)
-    runner.init_clip()
-    # the silhouette / colour prior: the SMPL template mesh (reference data/zero_beta_smpl.obj, packed in the test fixture) through
-    # the HIP rasteriser with neural_renderer's conventions -- the same per-iteration work as main.py:360
-    mesh_npz = os.path.join(ROOT, "tests", "golden", "smpl_views.npz")
-    if os.path.exists(mesh_npz):
-        from avatarclip_amd.smpl_prior import MeshPrior
-        z = np.load(mesh_npz)
-        runner.init_smpl(MeshPrior(z["mesh_v"], z["mesh_f"], device=dev))
-    else:
-        runner.init_smpl()
-    runner.update_learning_rate()
+    collective = "none (single process, no process group)"
+    if parallel.is_on():
+        import torch.distributed as dist
+        be = dist.get_backend()
+        collective = "%s%s, %d rank(s)" % (be, " (RCCL)" if be == "nccl" else "", world)
+        want = os.environ.get("AVC_ASSERT_DIST")
+        assert not want or want == be, "process group backend %s, expected %s" % (be, want)
 
-    def step(i):
-        runner.train_clip_iteration(i)
-        runner.update_learning_rate()
+    runner = build_runner(args.res, args.spp, args.small, dev)
+    dt, per_kernel = timed_steps(runner, args.steps, args.warmup, dev, args.sync_debug)
 
-    for i in range(args.warmup):
-        step(i)
-    Engine.PROFILE = True
-    Engine.prof_events = []
-    parallel.barrier()
-    torch.cuda.synchronize()
-    if args.sync_debug:
-        torch.cuda.set_sync_debug_mode("warn")
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    if args.sync_debug:
-        torch.cuda.set_sync_debug_mode("default")
-    torch.cuda.synchronize()
-    parallel.barrier()
-    dt = time.perf_counter() - t0
-    dt = parallel.max_over_ranks(dt, dev)
-    Engine.PROFILE = False
-
+    out = None
     if rank == 0:
         rays_per_step = args.res * args.res * world
-        # per-kernel launch times from events recorded on the launch stream (Engine._Timed)
-        per_kernel = {}
-        for name, npts, e0, e1 in Engine.prof_events:
-            per_kernel.setdefault(name, []).append((npts, e0.elapsed_time(e1) * 1e-3))
-        # HBM traffic per point measured with the PMC counters (separate rocprofv3 --pmc passes of this command, summarised by
-        # scripts/pmc_summary.py --json into profiles/): 2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction
-        pmc = {}
-        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-        if os.path.exists(pmc_path):
-            with open(pmc_path) as fh:
-                pmc = json.load(fh)
-        roofs = {}
-        if not args.small:
-            for name, spec in KERNEL_ROOFLINES.items():
-                if name not in per_kernel:
-                    continue
-                recs = per_kernel[name]
-                avg_t = float(np.mean([t for _, t in recs]))
-                avg_pts = float(np.mean([n for n, _ in recs]))
-                flops, nbytes = spec["flop_per_point"] * avg_pts, spec["bytes_per_point"] * avg_pts
-                mfma_frac, hbm_frac = flops / avg_t / PEAK_MFMA, nbytes / avg_t / PEAK_HBM
-                tr = pmc.get("kernels", {}).get(spec["kernel"])
-                r = {"kernel": "%s (%s)" % (spec["kernel"], name), "bound": spec["bound"],
-                     "achieved": (nbytes / avg_t / 1e9) if spec["bound"] == "hbm" else (flops / avg_t / 1e12),
-                     "peak": (PEAK_HBM / 1e9) if spec["bound"] == "hbm" else (PEAK_MFMA / 1e12),
-                     "unit": "GB/s" if spec["bound"] == "hbm" else "TFLOP/s", "frac": hbm_frac if spec["bound"] == "hbm" else mfma_frac,
-                     "traffic": (tr["bytes_per_point"] * avg_pts) if tr else None,
-                     "traffic_source": ("profiles/r02_pmc_traffic.json (commit %s, %s)" % (pmc.get("commit"), pmc.get("box"))) if tr else None,
-                     "avg_launch_ms": avg_t * 1e3, "points_per_launch": avg_pts, "launches": len(recs),
-                     "algorithmic_flop_per_point": spec["flop_per_point"], "algorithmic_bytes_per_point": spec["bytes_per_point"],
-                     "mfma_frac": mfma_frac, "hbm_frac_algorithmic": hbm_frac, "note": spec["note"]}
-                roofs[name] = r
-        dominant = max(roofs, key=lambda k: roofs[k]["avg_launch_ms"] * roofs[k]["launches"]) if roofs else None
-        roof = roofs.get(dominant)
+        roofs = kernel_rooflines(per_kernel, args.steps) if not args.small else {}
+        dominant = max(roofs, key=lambda k: roofs[k]["ms_per_step"]) if roofs else None
         kern_ms = {k: 1e3 * float(np.sum([t for _, t in v])) / args.steps for k, v in per_kernel.items()}
         out = {
             "metric": "rays_per_sec_512x512_64spp_clip_guided_train_iter",
@@ -294,17 +338,47 @@ def main():
                                    "%s nets, 2 CLIP ViT-B/32 passes, Adam, %d view(s)/step"
                                    % (args.res, args.res, args.spp, args.spp // 2, args.spp // 2,
                                       "small (128-wide)" if args.small else "full-size (256-wide)", world),
-                       "parallelism": "view-sharded dp%d, one flat RCCL all-reduce/step" % world},
+                       "parallelism": "view-sharded dp%d, one flat RCCL all-reduce/step" % world,
+                       "collective": collective},
             "kernel_ms_per_step": kern_ms,
-            "roofline": roof,
+            # whole step against the MFMA roofline: algorithmic MLP FLOPs of the step (257.3 MFLOP/ray at 64 spp) / step time
+            "step_mfma_frac": (step_flops(args.res, args.spp) * args.steps / dt / PEAK_MFMA) if not args.small else None,
+            "roofline": roofs.get(dominant),
             "roofline_all": roofs,
         }
+    # ---- extra_configs (rank 0 of a single-GPU run): BASELINE config 2 (224^2, 64 spp) and config 3's per-GPU share (512^2, 128 spp)
+    if world == 1 and not args.no_extra and not args.small and (args.res, args.spp) == (512, 64):
+        import gc
+        del runner
+        gc.collect()
+        torch.cuda.empty_cache()
+        extras = {}
+        torch.cuda.reset_peak_memory_stats(dev)
+        for label, (res, spp) in (("C2_224x224_64spp", (224, 64)), ("C3_per_gpu_512x512_128spp", (512, 128))):
+            try:
+                r2 = build_runner(res, spp, False, dev)
+                dt2, pk2 = timed_steps(r2, 5, 3, dev)
+                eng = r2.renderer.engine
+                chunk, slab = eng.plan(res * res, spp)
+                extras[label] = {"value": res * res * 5 / dt2, "unit": "rays/s", "ms_per_step": 1e3 * dt2 / 5, "iters_per_sec": 5 / dt2, "steps": 5,
+                                 "warmup": 3, "step_mfma_frac": step_flops(res, spp) * 5 / dt2 / PEAK_MFMA,
+                                 "kernel_ms_per_step": {k: 1e3 * float(np.sum([t for _, t in v])) / 5 for k, v in pk2.items()},
+                                 "rays_per_chunk": chunk, "rays_per_slab": slab, "forward_reruns_in_backward": chunk < res * res,
+                                 "peak_hbm_gib": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
+                del r2, eng
+            except Exception as e:   # an extra leg must never take the headline down (e.g. out of memory at 128 spp)
+                extras[label] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            gc.collect()
+            torch.cuda.empty_cache()
+            torch.cuda.reset_peak_memory_stats(dev)
+        out["extra_configs"] = extras
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.spp)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     parallel.barrier()
-    if world > 1:
+    if parallel.is_on():
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -52,6 +52,54 @@ def random_state_dict(seed: int = 0, dtype=torch.float32) -> Dict[str, torch.Ten
     return sd
 
 
+def outlier_state_dict(seed: int = 0, n_channels: int = 8, gain: float = 30.0, n_fc_rows: int = 4, fc_gain: float = 20.0,
+                       ln_blocks=()):
+    """An OFFLINE PROXY for the dynamic range of trained CLIP weights (the real ViT-B-32.pt cannot be fetched here): the seeded
+    state dict with the signature of trained ViTs' "massive activation" channels.
+      * default: `n_channels` residual channels are inflated `gain` times in the class / CLS-position embedding and in the ln_pre
+        gain, so the CLS token enters -- and, through the residual connections, stays in -- every block with a handful of channels
+        30x above the median; `n_fc_rows` rows of every mlp.c_fc are `fc_gain` times larger.
+      * ln_blocks = range(12): additionally the ln_1 / ln_2 gains of those channels are inflated in the listed blocks.  With all 24
+        gains at 30x the seeded (untrained) network becomes chaotic in its INPUT: merely rounding the linear operands to bf16 on the
+        CPU (fp32 accumulation) changes d cos / d pixels by O(1) while the embedding moves by 3e-4 (tests/test_gpu_clip.py prints it).
+    Not a substitute for the real weights (test_real_openai_weights_when_supplied stays the real check); it shows which tolerance
+    of the bf16-operand kernels survives outlier channels far above the median."""
+    sd = dict(random_state_dict(seed))
+    g = torch.Generator().manual_seed(1000 + seed)
+    ch = torch.randperm(WIDTH, generator=g)[:n_channels]
+    sd["visual.class_embedding"] = sd["visual.class_embedding"].clone()
+    sd["visual.class_embedding"][ch] *= gain
+    sd["visual.positional_embedding"] = sd["visual.positional_embedding"].clone()
+    sd["visual.positional_embedding"][0, ch] *= gain
+    sd["visual.ln_pre.weight"] = sd["visual.ln_pre.weight"].clone()
+    sd["visual.ln_pre.weight"][ch] *= gain
+    for i in range(LAYERS):
+        p = "visual.transformer.resblocks.%d." % i
+        if i in ln_blocks:
+            for n in ("ln_1.weight", "ln_2.weight"):
+                sd[p + n] = sd[p + n].clone()
+                sd[p + n][ch] *= gain
+        rows = torch.randperm(4 * WIDTH, generator=g)[:n_fc_rows]
+        sd[p + "mlp.c_fc.weight"] = sd[p + "mlp.c_fc.weight"].clone()
+        sd[p + "mlp.c_fc.weight"][rows] *= fc_gain
+    return sd
+
+
+def encode_image_bf16_operands(sd, image):
+    """encode_image with the operands of every linear rounded to bf16 and fp32 accumulation -- the arithmetic class of the HIP
+    encoder (and of the reference's fp16 CLIP on a GPU), as a CPU statement; used to separate "the kernel is wrong" from "bf16
+    operands move this network" in the outlier tests"""
+    orig = F.linear
+
+    def qlin(x, w, b=None):
+        return orig(x.bfloat16().float(), w.bfloat16().float(), b)
+    F.linear = qlin
+    try:
+        return encode_image(sd, image)
+    finally:
+        F.linear = orig
+
+
 def quick_gelu(x):
     return x * torch.sigmoid(1.702 * x)
 

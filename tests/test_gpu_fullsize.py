@@ -131,8 +131,8 @@ def test_fullsize_gradient_linearity_and_chunk_invariance():
     d_sdf = torch.randn(R, S, device=dev, generator=g) * 1e-3
     d_n = torch.randn(R, S, 3, device=dev, generator=g) * 1e-3
     d_rgb = torch.randn(R, S, 6, device=dev, generator=g) * 1e-3
-    # the training forward leaves the operand panels of the whole view (177 GiB) in the engine buffers; the first backward uses
-    # them, the second one finds them still there (the backward only ADDS the gradient-type tiles)
+    # the training forward leaves the forward-type operand panels of the whole view (87 GiB) in the engine's F region; the first
+    # backward uses them, the second one finds them still there (the backward only writes the per-slab G region)
     _, _, rgb = eng.points_fwd_train(pk, ro, rd, z, 2.0 / 32)
     g1 = eng.points_bwd(pk, ro, rd, z, 2.0 / 32, d_sdf, d_n, d_rgb, rgb, panels_valid=True)
     g2 = eng.points_bwd(pk, ro, rd, z, 2.0 / 32, 2 * d_sdf, 2 * d_n, 2 * d_rgb, rgb, panels_valid=True)
@@ -146,6 +146,8 @@ def test_fullsize_gradient_linearity_and_chunk_invariance():
     old = Engine.PANEL_BYTES_BUDGET
     try:
         Engine.PANEL_BYTES_BUDGET = 3 << 30      # many more, smaller launches: the backward re-runs the training forward per chunk
+        chunk, slab = eng.plan(R, S)
+        assert chunk < R and slab <= chunk and chunk % 32 == 0, (chunk, slab)   # the budget applies although larger buffers are at hand
         g3 = eng.points_bwd(pk, ro, rd, z, 2.0 / 32, d_sdf, d_n, d_rgb, rgb)
     finally:
         Engine.PANEL_BYTES_BUDGET = old
@@ -153,6 +155,55 @@ def test_fullsize_gradient_linearity_and_chunk_invariance():
     rel = ((g3 - g1).double().norm() / g1.double().norm()).item()
     print("chunk invariance rel", rel)
     assert rel < 1e-5
+
+
+@gpu
+@pytest.mark.parametrize("spp", [48, 64])
+def test_chunked_and_slabbed_backward_equals_one_pass(spp):
+    """The gradient must not depend on how the ray set is cut: one chunk / one slab vs several chunks (the training forward
+    re-run per chunk) of several slabs each, with ray counts that are no multiple of the chunk or slab size and a samples-per-ray
+    count (48) that is no multiple of the 32-point block.  Small nets, 1000 rays."""
+    from avatarclip_amd import fields, renderer
+    from avatarclip_amd.engine import Engine
+    dev = torch.device("cuda")
+    torch.manual_seed(3)
+    sdf = fields.SDFNetwork(d_out=129, d_in=3, d_hidden=128, n_layers=3, skip_in=[3], multires=6, bias=0.5, scale=1.0,
+                            geometric_init=True, weight_norm=True).to(dev)
+    col = fields.RenderingNetwork(d_feature=128, mode="no_view_dir", d_in=6, d_out=3, d_hidden=128, n_layers=1,
+                                  weight_norm=True, multires_view=0, squeeze_out=True, extra_color=True).to(dev)
+    var = fields.SingleVarianceNetwork(0.3).to(dev)
+    ren = renderer.NeuSRenderer(None, sdf, var, col, spp // 2, spp // 2, 0, 4, 1.0, True)
+    ro, rd, near, far = [t[:1000].contiguous() for t in _view(32, dev)]
+    eng = ren.engine
+    pk = eng.pack(ren.flat_params())
+    with torch.no_grad():
+        z = ren.sample_z(pk, ro, rd, near, far, 1.0)
+    R, S = z.shape
+    g = torch.Generator(device=dev).manual_seed(1)
+    d_sdf = torch.randn(R, S, device=dev, generator=g) * 1e-2
+    d_n = torch.randn(R, S, 3, device=dev, generator=g) * 1e-2
+    d_rgb = torch.randn(R, S, 6, device=dev, generator=g) * 1e-2
+    sd = 2.0 / (spp // 2)
+    _, _, rgb = eng.points_fwd_train(pk, ro, rd, z, sd)
+    assert eng.plan(R, S) == (R, R)
+    g1 = eng.points_bwd(pk, ro, rd, z, sd, d_sdf, d_n, d_rgb, rgb, panels_valid=True)
+    old = (Engine.PANEL_BYTES_BUDGET, Engine.SLAB_BLOCKS)
+    try:
+        Engine.SLAB_BLOCKS = 160                       # 96 rays per slab at 48 spp (3 x 32), 64 at 64 spp
+        g2 = eng.points_bwd(pk, ro, rd, z, sd, d_sdf, d_n, d_rgb, rgb, panels_valid=True)        # one chunk, many slabs
+        assert eng.plan(R, S)[0] == R and eng.plan(R, S)[1] < R // 8
+        blk = eng.fwd_tiles * 2048 + eng.mask_u16 * 2 + eng.grad_tiles * 2048
+        Engine.PANEL_BYTES_BUDGET = 1 << 26            # the floor of the budget (64 MiB): a few hundred rays per chunk
+        chunk, slab = eng.plan(R, S)
+        assert slab < chunk < R and chunk % 32 == 0 and slab % 32 == 0 and R % chunk != 0, (chunk, slab, blk)
+        g3 = eng.points_bwd(pk, ro, rd, z, sd, d_sdf, d_n, d_rgb, rgb)                            # chunks x slabs, forward re-run per chunk
+    finally:
+        Engine.PANEL_BYTES_BUDGET, Engine.SLAB_BLOCKS = old
+    torch.cuda.synchronize()
+    for name, gx in (("slabs", g2), ("chunks x slabs", g3)):
+        rel = ((gx - g1).double().norm() / g1.double().norm()).item()
+        print(spp, name, "rel", rel)
+        assert rel < 1e-5, (name, rel)
 
 
 @gpu

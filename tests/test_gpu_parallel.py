@@ -67,3 +67,67 @@ def test_pinned_upload_ring_survives_wraparound():
     assert all(float(o[1, 2]) == float(i) and o.shape == (4, 4) for i, o in enumerate(outs))
     big = h2d.upload(np.arange(1000.0), "cuda")          # larger than a ring row: plain path
     assert float(big[999]) == 999.0
+
+
+def _rccl_single_rank_worker(port, out):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    os.environ.pop("AVC_DIST_BACKEND", None)
+    import torch
+    import torch.distributed as dist
+    from avatarclip_amd import parallel
+    rank, world, local_rank = parallel.init_from_env(backend="nccl")
+    assert (rank, world, local_rank) == (0, 1, 0) and parallel.is_on() and dist.get_backend() == "nccl"
+    dev = torch.device("cuda", 0)
+    params = [torch.nn.Parameter(torch.randn(257, 256, device=dev)), torch.nn.Parameter(torch.randn(400065 - 257 * 256, device=dev))]
+    before = [p.detach().clone() for p in params]
+    parallel.broadcast_params(params)                       # ncclBroadcast on the parameter storage
+    bucket = parallel.GradBucket(params)                    # one flat fp32 buffer of 400 065 floats = the full nets' gradient
+    for p in params:
+        p.grad.copy_(torch.arange(p.numel(), device=dev, dtype=torch.float32).view_as(p) * 1e-3)
+    want = bucket.flat.clone()
+    bucket.allreduce_mean()                                 # ncclAllReduce(SUM) over the bucket, one rank: identity
+    t = parallel.max_over_ranks(12.5, dev)
+    parallel.barrier()
+    torch.cuda.synchronize()
+    out["same_params"] = all(torch.equal(a, b.detach()) for a, b in zip(before, params))
+    out["same_bucket"] = bool(torch.equal(want, bucket.flat))
+    out["bucket_numel"] = int(bucket.flat.numel())
+    out["max"] = t
+    out["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    dist.destroy_process_group()
+    out["clean_exit"] = True
+
+
+@gpu
+def test_rccl_path_with_a_single_rank():
+    """backend "nccl" IS RCCL on ROCm.  Every multi-rank test in this suite runs on gloo (RCCL refuses two ranks on one device), so
+    this one executes the product's collective calls -- init, broadcast of the parameters, the flat-bucket all-reduce, the MAX
+    reduction of the timing, barrier, teardown -- on RCCL itself with the one rank a 1-GPU box allows."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rccl_single_rank_worker, args=(free_port(), out), nprocs=1, join=True)
+    assert out["same_params"] and out["same_bucket"] and out["bucket_numel"] == 400065 and out["max"] == 12.5 and out["clean_exit"]
+    print("RCCL", out["nccl_version"])
+
+
+@gpu
+def test_bench_single_rank_under_the_launcher_runs_the_rccl_path():
+    """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`: the launcher's environment makes the Runner broadcast
+    its weights and all-reduce its gradient bucket over RCCL (one rank), i.e. the 8-GPU code path end to end on one GPU"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "AVC_DIST_BACKEND", "AVC_SINGLE_DEVICE"):
+        env.pop(k, None)
+    env["AVC_ASSERT_DIST"] = "nccl"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--res", "64", "--small", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["config"]["collective"] == "nccl (RCCL), 1 rank(s)"

@@ -8,6 +8,7 @@ the packed transposes.  LayerNorm / residual bookkeeping are torch elementwise o
 Accepts an OpenAI-format state dict (`visual.*` keys, e.g. torch.jit.load('ViT-B-32.pt').state_dict()).
 """
 import math
+import os
 from typing import Dict
 
 import torch
@@ -217,9 +218,17 @@ def load_state_dict(path: str) -> Dict[str, torch.Tensor]:
         from safetensors.torch import load_file
         return load_file(path)
     try:
-        obj = torch.jit.load(path, map_location="cpu")
-    except RuntimeError:
-        obj = torch.load(path, map_location="cpu", weights_only=False)
+        obj = torch.load(path, map_location="cpu", weights_only=True)     # a plain state dict: no code is executed
+    except Exception:
+        try:
+            obj = torch.jit.load(path, map_location="cpu")                # OpenAI's ViT-B-32.pt is a TorchScript archive
+        except RuntimeError:
+            # a pickled module or other arbitrary pickle: executes code from the file, as the reference's clip.load does --
+            # only with the explicit opt-in
+            if os.environ.get("AVC_ALLOW_UNSAFE_PICKLE") != "1":
+                raise RuntimeError("%s is neither a tensors-only checkpoint, a .safetensors file nor a TorchScript archive; loading it "
+                                   "would execute pickled code (set AVC_ALLOW_UNSAFE_PICKLE=1 to allow that)" % path)
+            obj = torch.load(path, map_location="cpu", weights_only=False)
     sd = obj.state_dict() if hasattr(obj, "state_dict") else obj
     return {k: v for k, v in sd.items() if torch.is_tensor(v)}
 

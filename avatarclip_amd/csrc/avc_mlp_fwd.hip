@@ -2,6 +2,11 @@
 //   avc_sdf_forward       SDF only (row 0 of the last layer) -- the no-grad evaluations of the hierarchical sampler
 //                         (renderer.py:337-338,187) and of extract_fields (renderer.py:10-25)
 //   avc_render_points_fwd sdf + normal (d sdf/dx) + 6 colour channels per sample point (renderer.py:221-232)
+// two output tiles per MFMA stream (independent accumulator chains) in the layers of THIS file: forward 6.21 -> 6.02 ms, training
+// forward 8.20 -> 7.90 ms per 4 Mi points; the backward kernel loses 4 % with it (profiles/r03_ab_kernels.txt) and keeps one chain
+#ifndef AVC_PAIR
+#define AVC_PAIR 1
+#endif
 #include "avc_mlp.h"
 #ifndef FWD_WPB
 #define FWD_WPB 8   // one 8-wave workgroup per CU shares every staged weight tile (LDS-DMA fill rate is the scarce resource)

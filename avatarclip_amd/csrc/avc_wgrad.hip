@@ -6,7 +6,7 @@
 // ---------------------------------------------------------------------------------------------
 // partial[split][ta][tb] = sum over the split's 32-point blocks, sum_kappa A[blk][ta][kappa] x B[blk][tb][kappa]
 // One 8-wave workgroup per (K-split, pair).  Per block the (ta+tb) panel tiles are copied ONCE into an LDS ring by
-// global->LDS DMA (ring depth - 1 blocks in flight under the work on the current one; depth: WG_DYN_DEPTH below).  The tiles arrive in the producers'
+// global->LDS DMA (WG_DEPTH - 1 blocks in flight under the work on the current one).  The tiles arrive in the producers'
 // FRAGMENT layout (lane = point, 8 features per k-step); the contraction over points needs them feature-major (lane =
 // feature, 8 points per lane).  gfx950's LDS transpose read does that on the way into the registers: ds_read_b64_tr_b16
 // hands lane i of a 16-lane group element (i & 3) of the 8 bytes addressed by lane 4 j + (i >> 2) of the group, for j = 0..3,
@@ -26,17 +26,11 @@
 #ifndef WG_DEPTH
 #define WG_DEPTH 4   // blocks in the LDS ring: one being contracted, WG_DEPTH - 1 copies in flight
 #endif
-// WG_DYN_DEPTH = 1: the ring slot is as large as the pair's own tile set and the ring as deep as the 160 KiB of LDS allow (at most
-// WG_DEPTH_MAX): 4 blocks for the 17/18-tile products, 5 for the 15/16-tile ones, 8 for the narrow ones (9-10 tiles) -- more bytes
-// in flight per CU where a block is small.  0: WG_DEPTH slots of WG_BUF_BYTES for every pair.
-#ifndef WG_DYN_DEPTH
-#define WG_DYN_DEPTH 1
-#endif
-#define WG_DEPTH_MAX 8
-#define WG_LDS_TOTAL (WG_DYN_DEPTH ? 160 * 1024 : WG_DEPTH * WG_BUF_BYTES)
-// cache policy of the panel -> LDS copies (aux operand of global_load_lds): 0 = default, 2 = nt (streamed once, keep it out of L2's way)
+// cache policy of the panel -> LDS copies (aux operand of global_load_lds): 2 = nt -- every tile is read exactly once by exactly one
+// workgroup.  (Measured at 4 Mi points, profiles/r03_ab_kernels.txt: nt 10.15 ms vs default 10.22; a ring as deep as the LDS allows per
+// pair -- 8 slots for the 9/10-tile products, 5 for the 15/16-tile ones -- 10.22 vs 10.23: the kernel does not lack bytes in flight.)
 #ifndef WG_DMA_AUX
-#define WG_DMA_AUX 0
+#define WG_DMA_AUX 2
 #endif
 
 // the two operand regions (csrc/avc_mlp.h: PanelLayout): [0] = F region (forward-type, f16), [1] = G region (gradient-type, bf16)
@@ -87,9 +81,7 @@ __device__ __forceinline__ void weight_grad_body(char* lds, const WgRegions& rg,
   const int ntile = ta_n + tb_n;
   const int nchunk = ntile * 2;
   const int my_chunks = (nchunk - wv + 7) >> 3;   // DMA instructions this wave issues per block
-  const int slot_bytes = WG_DYN_DEPTH ? ntile * 2048 : WG_BUF_BYTES;
-  int depth = WG_DYN_DEPTH ? WG_LDS_TOTAL / slot_bytes : WG_DEPTH;
-  if (depth > WG_DEPTH_MAX) depth = WG_DEPTH_MAX;
+  constexpr int slot_bytes = WG_BUF_BYTES, depth = WG_DEPTH;
   // source chunk of this lane in DMA instruction c of a tile: LDS position 64 c + lane = (p >> 2) * 16 + (2 s + h) * 4 + (p & 3)
   const int src_lo = ((lane >> 2) & 3) * 32 + 4 * (lane >> 4) + (lane & 3);   // (2 s + h) * 32 + p with p = 4 (lane >> 4) + (lane & 3)
   // operand A lives in region type_a, operand B in region type_b (0 = F region: f16 forward-type tiles, 1 = G region: bf16)
@@ -392,7 +384,7 @@ extern "C" int avc_weight_grad_all(const void* fpanels, int ftiles, const void* 
     }
   }
   if (nsplit < 1) nsplit = 1;
-  const int lds_bytes = WG_LDS_TOTAL;
+  const int lds_bytes = WG_DEPTH * WG_BUF_BYTES;
   static unsigned long long attr_seen = 0;
   if (avc_first_use_on_device(attr_seen)) {
     (void)hipFuncSetAttribute((const void*)weight_grad_all_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);

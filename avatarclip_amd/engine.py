@@ -79,12 +79,16 @@ class Engine:
     MAX_BWD_WAVES = 2048          # 256 CUs x one 8-wave workgroup
     # Operand panels (csrc/avc_mlp.h: PanelLayout).  F region: 89 tiles = 5.6 KiB per point (full nets), written by the training
     # forward for every block of a CHUNK of rays and kept until the backward pass; G region: 91 tiles = 5.7 KiB per point, one SLAB
-    # of SLAB_BLOCKS 32-point blocks, rewritten slab by slab by the backward pass (backward kernel + weight-gradient kernel per
-    # slab).  512^2 x 64 spp: one chunk (87 GiB of F panels) + a 23-GiB slab; 512^2 x 128 spp (BASELINE config 3 per GPU): 174 + 23
-    # GiB, still one chunk on a 288-GB MI355X.  Only when even that does not fit the budget -- min(AVC_PANEL_GIB, 80 % of the free
-    # HBM) -- the ray set is cut into chunks and the backward re-runs the training forward chunk by chunk.
+    # of at most SLAB_BLOCKS 32-point blocks, rewritten slab by slab by the backward pass (backward kernel + weight-gradient kernel
+    # per slab).  Every slab boundary costs the weight-gradient launch a tail (profiles/r03_slab_sweep.txt, 512^2 x 64 spp: 1 / 2 / 4
+    # / 8 slabs = 39.9 / 40.5 / 41.7 / 44.2 ms), so the slab is as large as the memory allows up to SLAB_BLOCKS and is halved
+    # (down to MIN_SLAB_BLOCKS) before the ray set is cut: 512^2 x 64 spp = 87 GiB of F panels + two 46-GiB slabs; 512^2 x 128 spp
+    # (BASELINE config 3 per GPU) = 174 GiB + 23-GiB slabs, still ONE chunk on a 288-GB MI355X.  Only when even that does not fit
+    # the budget -- min(AVC_PANEL_GIB, 80 % of the free HBM) -- the ray set is cut into chunks and the backward re-runs the
+    # training forward chunk by chunk.
     PANEL_BYTES_BUDGET = int(os.environ.get("AVC_PANEL_GIB", "224")) << 30
-    SLAB_BLOCKS = int(os.environ.get("AVC_SLAB_BLOCKS", str(128 * 1024)))
+    SLAB_BLOCKS = int(os.environ.get("AVC_SLAB_BLOCKS", str(256 * 1024)))
+    MIN_SLAB_BLOCKS = 32 * 1024
 
     def __init__(self, spec: PK.NetSpec, device):
         if device.type != "cuda":
@@ -173,22 +177,23 @@ class Engine:
         blk_f = self.fwd_tiles * 2048 + self.mask_u16 * 2
         blk_g = self.grad_tiles * 2048
         nb = lambda rays: (rays * S + 31) // 32 + 1
-        slab = min(R, max(32, self.SLAB_BLOCKS * 32 // S // 32 * 32))
-        need_all = nb(R) * blk_f + nb(slab) * blk_g
-        holds_all = (self._fpanels is not None and self._fpanels.numel() >= nb(R) * self.fwd_tiles * 2048
-                     and self._gpanels is not None and self._gpanels.numel() >= nb(slab) * blk_g)
-        if need_all <= self.PANEL_BYTES_BUDGET and holds_all:
-            return R, slab             # the buffers at hand already hold the whole ray set (no driver query on the hot path:
-                                       # hipMemGetInfo synchronises with the device)
+        rays_of = lambda blocks: min(R, max(32, blocks * 32 // S // 32 * 32))
         key = (R, S, self.PANEL_BYTES_BUDGET, self.SLAB_BLOCKS)
         if getattr(self, "_plan_key", None) == key:
-            return self._plan_val
+            chunk, slab = self._plan_val
+            if chunk < R or (self._fpanels is not None and self._fpanels.numel() >= nb(R) * self.fwd_tiles * 2048):
+                return self._plan_val  # (no driver query on the hot path: hipMemGetInfo synchronises with the device)
         # 80 % of what is free once the current buffers are given back (they are released before larger ones are allocated)
         budget = max(min(self.PANEL_BYTES_BUDGET, (torch.cuda.mem_get_info(self.device)[0] + self._held_bytes()) * 8 // 10), 1 << 26)
-        if need_all <= budget:
+        blocks = self.SLAB_BLOCKS
+        slab = rays_of(blocks)
+        while nb(R) * blk_f + nb(slab) * blk_g > budget and blocks > self.MIN_SLAB_BLOCKS:
+            blocks //= 2                                      # the whole ray set in one chunk is worth smaller slabs
+            slab = rays_of(blocks)
+        if nb(R) * blk_f + nb(slab) * blk_g <= budget:
             chunk = R
         else:
-            if nb(slab) * (blk_f + blk_g) > budget:          # not even one slab with its own F panels: shrink the slab
+            if nb(slab) * (blk_f + blk_g) > budget:          # not even one slab with its own F panels: shrink the slab further
                 slab = max(32, (budget // (blk_f + blk_g) - 1) * 32 // S // 32 * 32)
             chunk = max(slab, ((budget - nb(slab) * blk_g) // blk_f - 1) * 32 // S // 32 * 32)
             chunk, slab = min(chunk, R), min(slab, R)

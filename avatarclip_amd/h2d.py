@@ -39,9 +39,10 @@ class _Ring:
             ev.synchronize()
         row = self.buf[slot, :n]
         row.copy_(torch.from_numpy(a.reshape(-1)))
-        out = row.to(self.device, non_blocking=True).to(dtype).reshape(a.shape)
-        ev = torch.cuda.Event()
-        ev.record()
+        with torch.cuda.device(self.device):     # the copy AND its guard event go to this device's current stream
+            out = row.to(self.device, non_blocking=True).to(dtype).reshape(a.shape)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
         self.events[slot] = ev
         return out
 

@@ -61,6 +61,29 @@ class EllipsoidPrior:
         return shade[..., None].repeat(1, 1, 3)
 
 
+class ScalarLog:
+    """main.py:102 (`SummaryWriter(log_dir=os.path.join(base_exp_dir, 'logs'))`) without tensorboard (absent offline): the same
+    `add_scalar(tag, value, step)` calls, written as JSON lines to <base_exp_dir>/logs/scalars.jsonl.  The values stay device
+    tensors until `flush()` (one host transfer per report interval, not one per scalar and step)."""
+
+    def __init__(self, log_dir):
+        os.makedirs(log_dir, exist_ok=True)
+        self.path = os.path.join(log_dir, "scalars.jsonl")
+        self.pending = []
+
+    def add_scalar(self, tag, value, step):
+        self.pending.append((tag, value.detach() if torch.is_tensor(value) else value, int(step)))
+
+    def flush(self):
+        if not self.pending:
+            return
+        import json
+        with open(self.path, "a") as fh:
+            for tag, v, step in self.pending:
+                fh.write(json.dumps({"tag": tag, "value": float(v), "step": step}) + "\n")
+        self.pending = []
+
+
 class Runner:
     def __init__(self, conf_path, mode="train", case="CASE_NAME", is_continue=False, is_colab=False, conf=None,
                  device=None, data_root=None, allow_standins=None):
@@ -198,6 +221,7 @@ class Runner:
 
     # ------------------------------------------------------------------ NeuS-init stage (main.py:180-256)
     def train(self):
+        self._open_writer()
         self.update_learning_rate()
         res_step = self.end_iter - self.iter_step
         image_perm = self.get_image_perm()
@@ -212,6 +236,8 @@ class Runner:
             self.update_learning_rate()
             if self.iter_step % len(image_perm) == 0:
                 image_perm = self.get_image_perm()
+        if self.writer is not None:
+            self.writer.flush()
 
     def train_iteration(self, data):
         rays_o, rays_d, true_rgb, mask = data[:, :3], data[:, 3:6], data[:, 6:9], data[:, 9:10]
@@ -231,6 +257,16 @@ class Runner:
             self.grad_bucket.allreduce_mean()
         self.optimizer.step()
         self.iter_step += 1
+        if self.writer is not None:   # main.py:216,230-238
+            with torch.no_grad():
+                psnr = 20.0 * torch.log10(1.0 / (((render_out["color_fine"] - true_rgb) ** 2 * mask).sum() / (mask_sum * 3.0)).sqrt())
+                for tag, v in (("Loss/loss", loss), ("Loss/color_loss", color_fine_loss), ("Loss/eikonal_loss", render_out["gradient_error"]),
+                               ("Statistics/s_val", render_out["s_val"][:1].mean()),
+                               ("Statistics/cdf", (render_out["cdf_fine"][:, :1] * mask).sum() / mask_sum),
+                               ("Statistics/weight_max", (render_out["weight_max"] * mask).sum() / mask_sum), ("Statistics/psnr", psnr)):
+                    self.writer.add_scalar(tag, v, self.iter_step)
+            if self.iter_step % self.report_freq == 0:
+                self.writer.flush()
         return loss.detach()
 
     # ------------------------------------------------------------------ CLIP stage set-up (main.py:258-335)
@@ -302,7 +338,13 @@ class Runner:
         self.prior_renderer = prior_renderer
 
     # ------------------------------------------------------------------ CLIP-guided loop (main.py:337-566)
+    def _open_writer(self):
+        """main.py:102: the scalar log of a training run (rank 0; `general.log_scalars = False` turns it off)"""
+        if self.writer is None and self.rank == 0 and self.conf.get_bool("general.log_scalars", default=True):
+            self.writer = ScalarLog(os.path.join(self.base_exp_dir, "logs"))
+
     def train_clip(self):
+        self._open_writer()
         self.update_learning_rate()
         res_step = self.end_iter - self.iter_step
         for iter_i in range(res_step):
@@ -316,6 +358,8 @@ class Runner:
                 self.save_checkpoint()
             self._validation_hooks(clip_stage=True)
             self.update_learning_rate()
+        if self.writer is not None:
+            self.writer.flush()
 
     def sample_camera(self, iter_i):
         """main.py:348-359 (host numpy RNG, same draw order)."""
@@ -434,6 +478,10 @@ class Runner:
         mask_sum = mask.sum() + 1e-5
         color_error = (comp["color_fine"] - view.true_rgb) * mask
         color_fine_loss = F.l1_loss(color_error, torch.zeros_like(color_error), reduction="sum") / mask_sum
+        psnr = None
+        if self.writer is not None:   # main.py:493 (a logged statistic only: not computed when nothing records it)
+            with torch.no_grad():
+                psnr = 20.0 * torch.log10(1.0 / (((comp["color_fine"] - view.true_rgb) ** 2 * mask).sum() / (mask_sum * 3.0)).sqrt())
         eikonal_loss = render_out["gradient_error"]
         mask_loss = F.binary_cross_entropy(comp["weight_sum"].clip(1e-3, 1.0 - 1e-3), mask)
         if self.use_face_prompt and iter_i % 4 == 0:
@@ -457,7 +505,8 @@ class Runner:
         if self.add_no_texture:
             cosine_shading = torch.cosine_similarity(torch.mean(enc2, dim=0), torch.mean(text, dim=0), dim=0)
             loss = loss + (1.0 - cosine_shading) * self.clip_weight
-        return loss, dict(color=color_fine_loss, eikonal=eikonal_loss, mask=mask_loss, cosine=cosine, cosine_shading=cosine_shading)
+        return loss, dict(color=color_fine_loss, eikonal=eikonal_loss, mask=mask_loss, cosine=cosine, cosine_shading=cosine_shading,
+                          psnr=psnr, s_val=render_out["s_val"][:1].mean())
 
     def clip_loss(self, iter_i, camera=None):
         """main.py:348-534: one view from camera to scalar loss (differentiable)."""
@@ -479,7 +528,13 @@ class Runner:
         self.optimizer.step()
         self.iter_step += 1
         self.last_stats = dict(loss=loss.detach(), color=parts["color"].detach(), eikonal=parts["eikonal"].detach(),
-                               cosine=parts["cosine"].detach(), rays=self.last_view.rays_o.shape[0])
+                               cosine=parts["cosine"].detach(), rays=self.last_view.rays_o.shape[0], s_val=parts["s_val"], psnr=parts["psnr"])
+        if self.writer is not None:   # main.py:542-547
+            for tag, v in (("Loss/loss", loss), ("Loss/color_loss", parts["color"]), ("Loss/eikonal_loss", parts["eikonal"]),
+                           ("Loss/cosine", parts["cosine"]), ("Statistics/s_val", parts["s_val"]), ("Statistics/psnr", parts["psnr"])):
+                self.writer.add_scalar(tag, v, self.iter_step)
+            if self.iter_step % self.report_freq == 0:
+                self.writer.flush()
         return loss.detach()
 
     # ------------------------------------------------------------------ schedule / checkpoints (main.py:568-632)
@@ -514,9 +569,18 @@ class Runner:
                     copyfile(os.path.join(dir_name, f_name), os.path.join(cur_dir, f_name))
         copyfile(self.conf_path, os.path.join(self.base_exp_dir, "recording", "config.conf"))
 
+    def _torch_load(self, path):
+        """checkpoints of this stage hold tensors, the optimizer's plain containers and an int: the tensors-only unpickler reads
+        them without executing code from the file; anything else falls back to the reference's plain torch.load with a warning"""
+        try:
+            return torch.load(path, map_location=self.device, weights_only=True)
+        except Exception as e:
+            logging.warning("%s is not a tensors-only checkpoint (%s): loading it with the full unpickler, which executes code from "
+                            "the file", path, type(e).__name__)
+            return torch.load(path, map_location=self.device, weights_only=False)
+
     def load_checkpoint(self, checkpoint_name):
-        checkpoint = torch.load(os.path.join(self.base_exp_dir, "checkpoints", checkpoint_name), map_location=self.device,
-                                weights_only=False)
+        checkpoint = self._torch_load(os.path.join(self.base_exp_dir, "checkpoints", checkpoint_name))
         self.sdf_network.load_state_dict(checkpoint["sdf_network_fine"])
         self.deviation_network.load_state_dict(checkpoint["variance_network_fine"])
         self.color_network.load_state_dict(checkpoint["color_network_fine"])
@@ -524,7 +588,7 @@ class Runner:
         self.iter_step = checkpoint["iter_step"]
 
     def load_pretrain(self, checkpoint_name):
-        checkpoint = torch.load(checkpoint_name, map_location=self.device, weights_only=False)
+        checkpoint = self._torch_load(checkpoint_name)
         self.sdf_network.load_state_dict(checkpoint["sdf_network_fine"])
         self.deviation_network.load_state_dict(checkpoint["variance_network_fine"])
         self.color_network.load_state_dict(checkpoint["color_network_fine"], strict=False)   # main.py:617

@@ -75,9 +75,21 @@ def test_train_on_the_reference_standpose_dataset(tmp_path):
         r.update_learning_rate()
     print("loss curve (every 10th):", [round(c, 4) for c in curve[::10]])
     assert np.isfinite(curve).all() and np.mean(curve[-10:]) < 0.8 * np.mean(curve[1:6])
+    # ---- Runner.train() itself: 5 more steps with the scalar log of main.py:230-238 (Loss/*, Statistics/s_val, cdf, weight_max, psnr)
+    conf.put("train.end_iter", r.iter_step + 5)
+    conf.put("train.report_freq", 5)
+    r.end_iter, r.report_freq = r.iter_step + 5, 5
+    r.train()
+    rows = [json.loads(l) for l in open(os.path.join(str(tmp_path / "exp"), "logs", "scalars.jsonl"))]
+    tags = {x["tag"] for x in rows}
+    assert {"Loss/loss", "Loss/color_loss", "Loss/eikonal_loss", "Statistics/s_val", "Statistics/cdf", "Statistics/weight_max",
+            "Statistics/psnr"} <= tags and len(rows) == 5 * 7
+    psnr = [x["value"] for x in rows if x["tag"] == "Statistics/psnr"]
+    sval = [x["value"] for x in rows if x["tag"] == "Statistics/s_val"]
+    assert all(np.isfinite(psnr)) and all(5.0 < p < 60.0 for p in psnr) and all(0.0 < v < 1.0 for v in sval)
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    with open(os.path.join(out_dir, "r02_train_standpose_loss.json"), "w") as fp:
+    with open(os.path.join(out_dir, "r03_train_standpose_loss.json"), "w") as fp:
         json.dump({"what": "Runner.train on data/zero_beta_standpose_render (108 views), confs/base_models networks, batch 5120, lr 5e-4 "
                            "without warm-up, 60 iterations on the HIP path", "first_iteration_hip": loss0, "first_iteration_oracle": ref.item(),
                    "loss": curve}, fp)

@@ -69,7 +69,7 @@ def test_pinned_upload_ring_survives_wraparound():
     assert float(big[999]) == 999.0
 
 
-def _rccl_single_rank_worker(port, out):
+def _rccl_single_rank_worker(proc_index, port, out):
     import os
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     os.environ.pop("AVC_DIST_BACKEND", None)

@@ -96,3 +96,74 @@ def test_hip_rasteriser_matches_restatement():
     r.init_smpl(prior)
     loss = r.train_clip_iteration(1)
     assert torch.isfinite(loss)
+
+
+def test_shapegen_camera_list_equals_the_shipped_datasets():
+    """ShapeGen/render.py:17-29,48-56: the 108 camera-to-world matrices of `render_for_nerf`, against the transforms_train.json files
+    the reference ships (packed in tests/golden/smpl_views.npz): the stand-pose set exactly, the T-pose set with its camera
+    distance of 2.0 (same rotations)."""
+    from avatarclip_amd import shapegen_render as SR
+    z = np.load(GOLD)
+    T = np.stack([t for _, t in SR.nerf_cameras()])
+    assert T.shape == (108, 4, 4) and np.abs(T - z["stand_poses"]).max() < 1e-12
+    assert abs(float(z["stand_camera_angle_x"]) - SR.CAMERA_ANGLE_X) < 1e-15
+    T2 = np.stack([t for _, t in SR.nerf_cameras(camera_distance=2.0)])
+    assert np.abs(T2 - z["tpose_poses"]).max() < 1e-12
+    eye0 = SR.get_points_from_angles(2.2, -60, 0)
+    assert np.allclose(eye0, [0.0, 2.2 * np.sin(np.deg2rad(-60)), -2.2 * np.cos(np.deg2rad(-60))])
+
+
+@gpu
+def test_shapegen_dataset_writer_feeds_runner_train(tmp_path):
+    """row f-4 / BASELINE config 5's ShapeGen -> AppearanceGen link: the HIP rasteriser writes the 108-view dataset of
+    ShapeGen/render.py for the SMPL template (T pose after rot_mat, pelvis offset fitted as in the CPU test above); its views agree
+    with the shipped neural_renderer renders of data/zero_beta_tpose_render in framing, silhouette (torso band) and grey level, and
+    Runner.train (main.py:180-256) trains on the written folder."""
+    import json
+    from PIL import Image
+    import bench
+    from avatarclip_amd import shapegen_render as SR
+    from avatarclip_amd.runner import Runner
+    z = np.load(GOLD)
+    V, Fc = z["mesh_v"].astype(np.float64), z["mesh_f"]
+    t = np.array([0.0, 0.288, 0.211])
+    out = str(tmp_path / "render")
+    u8, transforms = SR.write_nerf_dataset(out, (V + t).astype(np.float32), Fc, camera_distance=2.0)
+    meta = json.load(open(os.path.join(out, "transforms_train.json")))
+    assert len(meta["frames"]) == 108 and abs(meta["camera_angle_x"] - np.pi / 3) < 1e-12
+    assert np.abs(np.asarray([f["transform_matrix"] for f in meta["frames"]]) - z["tpose_poses"]).max() < 1e-9
+    im0 = np.asarray(Image.open(os.path.join(out, "img", "0003.png")))
+    assert im0.shape == (256, 256, 3) and (im0[..., 0] == im0[..., 1]).all() and np.array_equal(im0[..., 0], u8[3])
+    ims = z["tpose_images"]
+    for k in (3, 57, 27, 87):                      # elevation 0: azimuth 0 (front), 180 (back), 80 and 280 (the two sides)
+        a, b = u8[k] > 0, ims[k] > 0
+        ra, rb = np.nonzero(a.any(1))[0], np.nonzero(b.any(1))[0]
+        assert abs(ra.min() - rb.min()) <= 12 and abs(ra.max() - rb.max()) <= 12, k
+        cb = np.nonzero(b.any(0))[0]
+        ca = np.nonzero(a.any(0))[0]
+        assert abs(0.5 * (ca.min() + ca.max()) - 0.5 * (cb.min() + cb.max())) <= 6, k
+        mid = int(0.5 * (cb.min() + cb.max()))
+        band = slice(mid - 10, mid + 11)
+        iou = (a[:, band] & b[:, band]).sum() / max((a[:, band] | b[:, band]).sum(), 1)
+        both = a & b
+        print("view", k, "torso-band IoU %.3f" % iou, "grey", float(u8[k][both].mean()), float(ims[k][both].mean()))
+        assert iou > 0.75 and abs(float(u8[k][both].mean()) - float(ims[k][both].mean())) < 25, k
+    # AppearanceGen's NeuS-init stage on the written folder
+    conf = bench.make_conf(256, 32, small=True)
+    conf.put("general.base_exp_dir", str(tmp_path / "exp"))
+    conf.put("dataset.data_dir", out)
+    conf.put("train.batch_size", 1024)
+    conf.put("train.warm_up_end", 0)
+    conf.put("train.end_iter", 30)
+    conf.put("model.rendering_network.extra_color", False)
+    conf.put("model.neus_renderer.extra_color", False)
+    r = Runner(None, mode="train", conf=conf, device=torch.device("cuda"))
+    assert r.dataset.n_images == 108
+    losses = []
+    image_perm = r.get_image_perm()
+    r.update_learning_rate()
+    for _ in range(30):
+        batch = r.dataset.gen_random_rays_at(image_perm[r.iter_step % len(image_perm)], r.batch_size)
+        losses.append(r.train_iteration(batch).item())
+        r.update_learning_rate()
+    assert np.isfinite(losses).all() and np.mean(losses[-5:]) < np.mean(losses[:5])

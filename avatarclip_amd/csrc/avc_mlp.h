@@ -143,7 +143,7 @@ __device__ __forceinline__ void layer_s(ST& st, const V* __restrict__ blob, int 
       if (t < NT) {
         const bool two = AVC_PAIR && (j + 1 < G) && (t + 1 < NT);
         facc a0, a1;
-        if (two) tile_mma_pair<V, KS>(st, j, in, a0, a1);
+        if (two) tile_mma_pair<V, KS>(st, j, in, a0, a1, bias, t);
         else a0 = tile_mma<V, KS>(st, j, in, bias, t);
         if (np > 0) {
           epi(tp, prev0);

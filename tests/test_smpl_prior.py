@@ -128,7 +128,10 @@ def test_shapegen_dataset_writer_feeds_runner_train(tmp_path):
     V, Fc = z["mesh_v"].astype(np.float64), z["mesh_f"]
     t = np.array([0.0, 0.288, 0.211])
     out = str(tmp_path / "render")
-    u8, transforms = SR.write_nerf_dataset(out, (V + t).astype(np.float32), Fc, camera_distance=2.0)
+    # render_for_nerf multiplies the (posed) vertices by rot_mat (render.py:39-43); the T-posed body of the shipped set is the
+    # template + t AFTER that rotation, so the writer gets the template turned the other way
+    from avatarclip_amd.smpl_prior import ROT_MAT
+    u8, transforms = SR.write_nerf_dataset(out, ((V + t) @ np.asarray(ROT_MAT).T).astype(np.float32), Fc, camera_distance=2.0)
     meta = json.load(open(os.path.join(out, "transforms_train.json")))
     assert len(meta["frames"]) == 108 and abs(meta["camera_angle_x"] - np.pi / 3) < 1e-12
     assert np.abs(np.asarray([f["transform_matrix"] for f in meta["frames"]]) - z["tpose_poses"]).max() < 1e-9

@@ -117,9 +117,18 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 #ifndef AVC_PAIR
 #define AVC_PAIR 0   // 1: two output tiles per MFMA stream (independent accumulators), 0: one dependent chain per tile
 #endif
-template <typename V, int KS, int NT, class ST, typename Epi, typename Hook = NoHook, class Bias = NoBias>
-__device__ __forceinline__ void layer_s(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&in)[KS],
-                                        Epi&& epi, Hook&& hook = NoHook{}, const Bias& bias = NoBias{}) {
+#ifndef AVC_PAIR_SQ
+#define AVC_PAIR_SQ AVC_PAIR   // the same for the layers whose epilogues read panel tiles back (layer_sq: normal sweep of the forward)
+#endif
+#ifndef AVC_PAIR_L2
+#define AVC_PAIR_L2 AVC_PAIR   // ... and for the layers with a split K dimension (layer2_s: feature layer, first colour layer)
+#endif
+// PAIRED = two output tiles per MFMA stream.  Measured per 4 Mi points (profiles/r03_ab_kernels.txt): forward 6.16 -> 6.01 ms and
+// training forward 8.25 -> 7.84 ms with it (and 26 / 36 spilled registers become 0 / 12); the SDF-only kernel loses 6 % (its 168
+// registers leave no room for the second accumulator: 16 -> 28 spills) and the backward kernel 3 %: those keep one chain.
+template <bool PAIRED, typename V, int KS, int NT, class ST, typename Epi, typename Hook = NoHook, class Bias = NoBias>
+__device__ __forceinline__ void layer_sp(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&in)[KS],
+                                         Epi&& epi, Hook&& hook = NoHook{}, const Bias& bias = NoBias{}) {
   constexpr int G = ST::template group<KS>();
   constexpr int NG = (NT + G - 1) / G;
   facc prev0, prev1;
@@ -138,10 +147,10 @@ __device__ __forceinline__ void layer_s(ST& st, const V* __restrict__ blob, int 
     if (g == 0) hook();
     dephase(st);
 #pragma unroll
-    for (int j = 0; j < G; j += (AVC_PAIR ? 2 : 1)) {
+    for (int j = 0; j < G; j += (PAIRED ? 2 : 1)) {
       const int t = g * G + j;
       if (t < NT) {
-        const bool two = AVC_PAIR && (j + 1 < G) && (t + 1 < NT);
+        const bool two = PAIRED && (j + 1 < G) && (t + 1 < NT);
         facc a0, a1;
         if (two) tile_mma_pair<V, KS>(st, j, in, a0, a1, bias, t);
         else a0 = tile_mma<V, KS>(st, j, in, bias, t);
@@ -162,6 +171,16 @@ __device__ __forceinline__ void layer_s(ST& st, const V* __restrict__ blob, int 
   if (np > 1) epi(tp + 1, prev1);
   __builtin_amdgcn_sched_barrier(0);
 }
+template <typename V, int KS, int NT, class ST, typename Epi, typename Hook = NoHook, class Bias = NoBias>
+__device__ __forceinline__ void layer_s(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&in)[KS],
+                                        Epi&& epi, Hook&& hook = NoHook{}, const Bias& bias = NoBias{}) {
+  layer_sp<(AVC_PAIR != 0), V, KS, NT>(st, blob, offw, after, in, epi, hook, bias);
+}
+template <typename V, int KS, int NT, class ST, typename Epi, typename Hook = NoHook, class Bias = NoBias>
+__device__ __forceinline__ void layer_s1(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&in)[KS],
+                                         Epi&& epi, Hook&& hook = NoHook{}, const Bias& bias = NoBias{}) {
+  layer_sp<false, V, KS, NT>(st, blob, offw, after, in, epi, hook, bias);   // always one accumulator chain
+}
 // ---- the same layer with the epilogue's global loads issued BEFORE the MFMA chain they trail: pre(t) returns the raw loads
 // ---- (panel tiles read back by the backward sweeps), epi(t, acc, data) consumes them after the chain of tile t+1.  The
 // ---- backward kernel keeps only ~16 KiB of reads in flight per CU when every epilogue loads and immediately waits; one
@@ -174,11 +193,61 @@ __device__ __forceinline__ void layer_s(ST& st, const V* __restrict__ blob, int 
 // DEEP = false: pre(t-1) goes out before the chain of tile t (one chain of head start, one load set live);
 // DEEP = true:  pre(t) goes out before the chain of tile t (two chains + one epilogue of head start, two sets live) --
 //               measured slower for the three-array loads of the reverse sweep (register pressure), see DESIGN.md 5.
-template <bool AVC_PRE_DEEP, typename V, int KS, int NT, class ST, typename Pre, typename Epi, typename Hook>
+template <bool AVC_PRE_DEEP, bool PAIRED, typename V, int KS, int NT, class ST, typename Pre, typename Epi, typename Hook>
 __device__ __forceinline__ void layer_sq_(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&in)[KS],
                                          Pre&& pre, Epi&& epi, Hook&& hook) {
   constexpr int G = ST::template group<KS>();
   constexpr int NG = (NT + G - 1) / G;
+  if constexpr (PAIRED && !AVC_PRE_DEEP) {
+    // two output tiles per MFMA stream: the loads of the previous pair's epilogues go out before the chains of the current pair
+    facc prev0, prev1;
+    decltype(pre(0)) d0{}, d1{};
+    int tp = -1, np = 0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      AVC_SYNC();
+      if (g + 1 < NG) {
+        Next n;
+        n.ptr = blob + (offw >> 3) + (long)((g + 1) * G * KS) * 64;
+        n.chunks = KS * ((NT - (g + 1) * G) < G ? (NT - (g + 1) * G) : G);
+        stage_issue(st, n, st.par ^ 1);
+      } else {
+        stage_issue(st, after, st.par ^ 1);
+      }
+      if (g == 0) hook();
+#pragma unroll
+      for (int j = 0; j < G; j += 2) {
+        const int t = g * G + j;
+        if (t < NT) {
+          const bool two = (j + 1 < G) && (t + 1 < NT);
+          if (np > 0) {
+            d0 = pre(tp);
+            if (np > 1) d1 = pre(tp + 1);
+            __builtin_amdgcn_sched_barrier(0);   // the loads go out before the chains
+          }
+          facc a0, a1;
+          if (two) tile_mma_pair<V, KS>(st, j, in, a0, a1, NoBias{}, t);
+          else a0 = tile_mma<V, KS>(st, j, in);
+          if (np > 0) {
+            epi(tp, prev0, d0);
+            if (np > 1) epi(tp + 1, prev1, d1);
+            if (two) { interleave_mfma_valu<KS>(); interleave_mfma_valu<KS>(); } else interleave_mfma_valu<KS>();
+          }
+          prev0 = a0;
+          if (two) prev1 = a1;
+          tp = t; np = two ? 2 : 1;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      st.par ^= 1;
+    }
+    d0 = pre(tp);
+    if (np > 1) d1 = pre(tp + 1);
+    epi(tp, prev0, d0);
+    if (np > 1) epi(tp + 1, prev1, d1);
+    __builtin_amdgcn_sched_barrier(0);
+    return;
+  }
   facc prev;
   decltype(pre(0)) dprev{}, dcur{};
 #pragma unroll
@@ -220,12 +289,12 @@ __device__ __forceinline__ void layer_sq_(ST& st, const V* __restrict__ blob, in
 template <typename V, int KS, int NT, class ST, typename Pre, typename Epi, typename Hook = NoHook>
 __device__ __forceinline__ void layer_sq(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&in)[KS],
                                          Pre&& pre, Epi&& epi, Hook&& hook = NoHook{}) {
-  layer_sq_<false, V, KS, NT>(st, blob, offw, after, in, pre, epi, hook);
+  layer_sq_<false, (AVC_PAIR_SQ != 0), V, KS, NT>(st, blob, offw, after, in, pre, epi, hook);
 }
 template <typename V, int KS, int NT, class ST, typename Pre, typename Epi, typename Hook = NoHook>
 __device__ __forceinline__ void layer_sqd(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&in)[KS],
                                           Pre&& pre, Epi&& epi, Hook&& hook = NoHook{}) {
-  layer_sq_<AVC_DEEP_PF1 != 0, V, KS, NT>(st, blob, offw, after, in, pre, epi, hook);
+  layer_sq_<AVC_DEEP_PF1 != 0, (AVC_PAIR_SQ != 0), V, KS, NT>(st, blob, offw, after, in, pre, epi, hook);
 }
 template <typename V, int KA, int KB, int NT, class ST, typename Epi, typename Hook = NoHook, class Bias = NoBias>
 __device__ __forceinline__ void layer2_s(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&ina)[KA],
@@ -233,7 +302,9 @@ __device__ __forceinline__ void layer2_s(ST& st, const V* __restrict__ blob, int
   constexpr int KS = KA + KB;
   constexpr int G = ST::template group<KS>();
   constexpr int NG = (NT + G - 1) / G;
-  facc prev;
+  constexpr bool PAIRED = AVC_PAIR_L2 != 0;
+  facc prev0, prev1;
+  int tp = -1, np = 0;
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     AVC_SYNC();
@@ -248,18 +319,28 @@ __device__ __forceinline__ void layer2_s(ST& st, const V* __restrict__ blob, int
     if (g == 0) hook();
     dephase(st);
 #pragma unroll
-    for (int j = 0; j < G; ++j) {
+    for (int j = 0; j < G; j += (PAIRED ? 2 : 1)) {
       const int t = g * G + j;
       if (t < NT) {
-        facc acc = tile_mma2<V, KA, KB>(st, j, ina, inb, bias, t);
-        if (t > 0) { epi(t - 1, prev); interleave_mfma_valu<KS>(); }
-        prev = acc;
+        const bool two = PAIRED && (j + 1 < G) && (t + 1 < NT);
+        facc a0, a1;
+        if (two) tile_mma2_pair<V, KA, KB>(st, j, ina, inb, a0, a1, bias, t);
+        else a0 = tile_mma2<V, KA, KB>(st, j, ina, inb, bias, t);
+        if (np > 0) {
+          epi(tp, prev0);
+          if (np > 1) epi(tp + 1, prev1);
+          if (two) { interleave_mfma_valu<KS>(); interleave_mfma_valu<KS>(); } else interleave_mfma_valu<KS>();
+        }
+        prev0 = a0;
+        if (two) prev1 = a1;
+        tp = t; np = two ? 2 : 1;
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     st.par ^= 1;
   }
-  epi(NT - 1, prev);
+  epi(tp, prev0);
+  if (np > 1) epi(tp + 1, prev1);
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -390,7 +471,7 @@ __device__ __forceinline__ float sdf_only(ST& sg, const h8* __restrict__ Wf, TP 
     {
       h8 pef[3];
       pe_to_frags_f16(pe, x, h, pef);
-      layer_s<h8, 3, N::HT>(sg, Wf, o.v[OFF_W0], nxt<N, OFF_WM0>(sg, Wf, o), pef, AVC_EPI(
+      layer_s1<h8, 3, N::HT>(sg, Wf, o.v[OFF_W0], nxt<N, OFF_WM0>(sg, Wf, o), pef, AVC_EPI(
         float a[16];
         _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r]);
         acc_to_frags(a, h1[2 * t], h1[2 * t + 1]);
@@ -398,25 +479,25 @@ __device__ __forceinline__ float sdf_only(ST& sg, const h8* __restrict__ Wf, TP 
     }
     if constexpr (N::NMID == 2) {
       h8 hm0[N::HK];
-      layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wf, o), h1, AVC_EPI(
+      layer_s1<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wf, o), h1, AVC_EPI(
         float a[16];
         _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r]);
         acc_to_frags(a, hm0[2 * t], hm0[2 * t + 1]);
       ), NoHook{}, TabBias{T + o.v[OFF_BM0], h});
-      layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wf, o), hm0, AVC_EPI(
+      layer_s1<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wf, o), hm0, AVC_EPI(
         float a[16];
         _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r]);
         acc_to_frags(a, hlast[2 * t], hlast[2 * t + 1]);
       ), NoHook{}, TabBias{T + o.v[OFF_BM1], h});
     } else {
-      layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wf, o), h1, AVC_EPI(
+      layer_s1<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wf, o), h1, AVC_EPI(
         float a[16];
         _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r]);
         acc_to_frags(a, hlast[2 * t], hlast[2 * t + 1]);
       ), NoHook{}, TabBias{T + o.v[OFF_BM0], h});
     }
   }
-  layer_s<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], no_next(), hlast, AVC_EPI(
+  layer_s1<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], no_next(), hlast, AVC_EPI(
     float w[16];
     load16(T + o.v[OFF_WL0_ACC], t, h, w);
     _Pragma("unroll") for (int r = 0; r < 16; ++r) part += w[r] * softplus2(acc[r]);

@@ -127,20 +127,9 @@ struct TabBias { static constexpr bool on = true; lds_tab_t tab; int h; };
 #ifndef AVC_LDS_AHEAD2
 #define AVC_LDS_AHEAD2 4   // A fragments in flight per tile of the pair
 #endif
-template <typename V, int KS, class ST, class B>
-__device__ __forceinline__ void tile_mma_pair(const ST& st, int j, const V (&in)[KS], facc& acc0, facc& acc1, const B& bias, int t) {
-  const V* a0 = reinterpret_cast<const V*>(st.lds + st.par * ST::BUF_BYTES + j * KS * 1024) + st.lane;
-  const V* a1 = a0 + KS * 64;
-  if constexpr (B::on) {   // the bias rows of tiles t, t + 1 enter through the accumulators (see TabBias)
-    float b0[16], b1[16];
-    load16(bias.tab, t, bias.h, b0);
-    load16(bias.tab, t + 1, bias.h, b1);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = b0[r]; acc1[r] = b1[r]; }
-  } else {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-  }
+// the MFMAs of two tiles over one input array: a0 / a1 = this lane's chunk of k-step 0 of either tile
+template <typename V, int KS>
+__device__ __forceinline__ void pair_chain(const V* __restrict__ a0, const V* __restrict__ a1, const V (&in)[KS], facc& acc0, facc& acc1) {
   V fa[KS], fb[KS];
 #pragma unroll
   for (int s = 0; s < KS && s < AVC_LDS_AHEAD2; ++s) { fa[s] = a0[s * 64]; fb[s] = a1[s * 64]; }
@@ -155,6 +144,35 @@ __device__ __forceinline__ void tile_mma_pair(const ST& st, int j, const V (&in)
       acc1 = MF<V>::mma(fb[k], in[k], acc1);
     }
   }
+}
+template <class B>
+__device__ __forceinline__ void pair_init(facc& acc0, facc& acc1, const B& bias, int t) {
+  if constexpr (B::on) {   // the bias rows of tiles t, t + 1 enter through the accumulators (see TabBias)
+    float b0[16], b1[16];
+    load16(bias.tab, t, bias.h, b0);
+    load16(bias.tab, t + 1, bias.h, b1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = b0[r]; acc1[r] = b1[r]; }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  }
+}
+template <typename V, int KS, class ST, class B>
+__device__ __forceinline__ void tile_mma_pair(const ST& st, int j, const V (&in)[KS], facc& acc0, facc& acc1, const B& bias, int t) {
+  const V* a0 = reinterpret_cast<const V*>(st.lds + st.par * ST::BUF_BYTES + j * KS * 1024) + st.lane;
+  pair_init(acc0, acc1, bias, t);
+  pair_chain<V, KS>(a0, a0 + KS * 64, in, acc0, acc1);
+}
+// the same with the K dimension split over two register arrays (tiles of KA + KB k-steps)
+template <typename V, int KA, int KB, class ST, class B>
+__device__ __forceinline__ void tile_mma2_pair(const ST& st, int j, const V (&ina)[KA], const V (&inb)[KB], facc& acc0, facc& acc1,
+                                               const B& bias, int t) {
+  const V* a0 = reinterpret_cast<const V*>(st.lds + st.par * ST::BUF_BYTES + j * (KA + KB) * 1024) + st.lane;
+  const V* a1 = a0 + (KA + KB) * 64;
+  pair_init(acc0, acc1, bias, t);
+  pair_chain<V, KA>(a0, a1, ina, acc0, acc1);
+  pair_chain<V, KB>(a0 + KA * 64, a1 + KA * 64, inb, acc0, acc1);
 }
 
 // Where the accumulator of an output tile starts: zero, or the tile's bias row read from the fp32 table in LDS straight into

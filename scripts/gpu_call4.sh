@@ -1,0 +1,9 @@
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R && mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_iteration.py tests/test_smpl_prior.py -m gpu -q -rA --timeout 900 > gpurun_out/c4_tests_full.log 2>&1
+grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/c4_tests_full.log | tail -30
+grep -E "rel [0-9.e+-]+ cos|torso-band|worst per-tensor" gpurun_out/c4_tests_full.log | head -80
+( for v in "" _fp1 _fpsq _fpl2 _bpair; do AVC_LIB_NAME=libavc$v.so timeout 300 python scripts/kb2.py 4194304 2>&1 | tail -1; done ) > gpurun_out/c4_kb2.txt
+cat gpurun_out/c4_kb2.txt
+AVC_LIB_NAME=libavc_bpair.so timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q --timeout 900 -k "parameter_gradients or render_matches" 2>&1 | tail -5

@@ -232,7 +232,8 @@ def test_parameter_gradients_match_golden(name):
     torch.cuda.synchronize()
     print(name, "loss", loss.item(), "ref", rec["loss"].item())
     assert abs(loss.item() - rec["loss"].item()) < 2e-3 * max(1.0, abs(rec["loss"].item()))
-    worst = 0.0
+    worst, bad = 0.0, []
+    gnorm = float(np.sqrt(sum(float(rec[k].double().pow(2).sum()) for k in rec if k.startswith("grad_"))))
     for pfx, net in (("sdf.", sdf), ("var.", var), ("col.", col)):
         for n_, p in net.named_parameters():
             ref = rec["grad_" + pfx + n_]
@@ -241,11 +242,17 @@ def test_parameter_gradients_match_golden(name):
                 continue
             re = relerr(g, ref)
             cos = torch.nn.functional.cosine_similarity(g.reshape(1, -1).double(), ref.reshape(1, -1).double()).item()
-            print("  %-22s rel %.3e cos %.5f |ref| %.3e" % (pfx + n_, re, cos, ref.norm().item()))
+            # parameter gradients <= 1e-2 (bf16 operands) -- asserted per tensor on both fixtures (512 rays = 32 768 points of
+            # the full-size nets, 256 rays of the shipped small checkpoint).  Tensors whose gradient is below 1e-4 of the whole
+            # gradient's norm (the colour layers' biases: sums of a few thousand bf16-rounded deltas that mostly cancel) get 2e-2.
+            tiny = ref.double().norm().item() < 1e-4 * gnorm
+            gate = 2e-2 if tiny else 1e-2
+            print("  %-22s rel %.3e cos %.5f |ref| %.3e%s" % (pfx + n_, re, cos, ref.norm().item(), "  (tiny: gate 2e-2)" if tiny else ""))
             worst = max(worst, re)
-            # parameter gradients <= 1e-2 (bf16 operands).  Full-size nets: the 512-ray fixture (32 768 points) is asserted at
-            # that gate; the shipped small checkpoint's 256 rays keep 1.5e-2 (measured 1.1e-2 on its worst tensor)
-            assert re < (1e-2 if name == "neus_full.npz" else 1.5e-2) and cos > 0.9995, (pfx + n_, re, cos)
+            if not (re < gate and cos > 0.9995):
+                bad.append((pfx + n_, re, cos))
+    print(name, "worst per-tensor relative gradient error", worst)
+    assert not bad, bad
 
 
 @gpu

@@ -244,10 +244,11 @@ def test_parameter_gradients_match_golden(name):
             cos = torch.nn.functional.cosine_similarity(g.reshape(1, -1).double(), ref.reshape(1, -1).double()).item()
             # parameter gradients <= 1e-2 (bf16 operands) -- asserted per tensor on both fixtures (512 rays = 32 768 points of
             # the full-size nets, 256 rays of the shipped small checkpoint).  Tensors whose gradient is below 1e-4 of the whole
-            # gradient's norm (the colour layers' biases: sums of a few thousand bf16-rounded deltas that mostly cancel) get 2e-2.
+            # gradient's norm (in these fixtures' loss: the whole colour branch, whose gradient is three orders below the SDF net's) get
+            # 1.5e-2; measured worst 1.1e-2 (colour layer 0 of the full nets: ReLU sign flips of f16 pre-activations), SDF tensors <= 3.4e-3.
             tiny = ref.double().norm().item() < 1e-4 * gnorm
-            gate = 2e-2 if tiny else 1e-2
-            print("  %-22s rel %.3e cos %.5f |ref| %.3e%s" % (pfx + n_, re, cos, ref.norm().item(), "  (tiny: gate 2e-2)" if tiny else ""))
+            gate = 1.5e-2 if tiny else 1e-2
+            print("  %-22s rel %.3e cos %.5f |ref| %.3e%s" % (pfx + n_, re, cos, ref.norm().item(), "  (tiny: gate 1.5e-2)" if tiny else ""))
             worst = max(worst, re)
             if not (re < gate and cos > 0.9995):
                 bad.append((pfx + n_, re, cos))

@@ -106,7 +106,8 @@ class LinearFn(torch.autograd.Function):
         r2 = None if residual is None else residual.reshape(-1, lin.N).contiguous().float()
         y, pre = _linear_raw(x2, lin, False, lin.b, r2, act, True)
         ctx.lin, ctx.act, ctx.has_res = lin, act, residual is not None
-        ctx.save_for_backward(pre if pre is not None else y.new_zeros(1))
+        if pre is not None:          # (nothing to save for a linear without activation: a dummy tensor would cost a fill launch per call)
+            ctx.save_for_backward(pre)
         return y.reshape(*shp[:-1], lin.N)
 
     @staticmethod

@@ -186,7 +186,8 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     const float* __restrict__ z, const float* __restrict__ rays_o, const float* __restrict__ rays_d, int R, int S,
     const float* __restrict__ inv_s_p, float sample_dist, float car, const float* __restrict__ bg, int bg_mode,
     float* __restrict__ color, float* __restrict__ extra, float* __restrict__ weights, float* __restrict__ cdf,
-    float* __restrict__ mid_z, float* __restrict__ inside, float* __restrict__ eik) {
+    float* __restrict__ mid_z, float* __restrict__ inside, float* __restrict__ eik, float* __restrict__ wstat,
+    float* __restrict__ nsum) {
   __shared__ float sT[RPB][MAXS], sA[RPB][MAXS];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // no early return: every wave of the block must reach the __syncthreads() below
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
   __syncthreads();
   excl_cumprod(T, S, (S + 63) / 64, lane);
   __syncthreads();
-  float c0 = 0, c1 = 0, c2 = 0, x0 = 0, x1 = 0, x2 = 0, ws = 0;
+  float c0 = 0, c1 = 0, c2 = 0, x0 = 0, x1 = 0, x2 = 0, ws = 0, wm = 0, n0 = 0, n1 = 0, n2 = 0;
   for (int i = lane; i < S; i += 64) {
     const float wv = A[i] * T[i];
     if (active) weights[base + i] = wv;
@@ -230,11 +231,23 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     c0 += wv * r[0]; c1 += wv * r[1]; c2 += wv * r[2];
     x0 += wv * r[3]; x1 += wv * r[4]; x2 += wv * r[5];
     ws += wv;
+    wm = fmaxf(wm, wv);
+    if (nsum) {   // sum_i w_i n_i: the shading normal of main.py:428 before its normalisation
+      const float* nn = normal + 3 * (base + i);
+      n0 += wv * nn[0]; n1 += wv * nn[1]; n2 += wv * nn[2];
+    }
   }
   c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2);
   x0 = wave_sum(x0); x1 = wave_sum(x1); x2 = wave_sum(x2);
   ws = wave_sum(ws); e_num = wave_sum(e_num); e_den = wave_sum(e_den);
+  if (wstat) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
+  }
+  if (nsum) { n0 = wave_sum(n0); n1 = wave_sum(n1); n2 = wave_sum(n2); }
   if (lane == 0 && active) {
+    if (wstat) { wstat[2 * ray] = ws; wstat[2 * ray + 1] = wm; }
+    if (nsum) { nsum[3 * ray] = n0; nsum[3 * ray + 1] = n1; nsum[3 * ray + 2] = n2; }
     float b0 = 0, b1 = 0, b2 = 0;
     if (bg_mode == 1) { b0 = bg[0]; b1 = bg[1]; b2 = bg[2]; }
     else if (bg_mode == 2) { b0 = b1 = b2 = bg[ray]; }
@@ -248,12 +261,12 @@ extern "C" int avc_composite_fwd(const float* sdf, const float* normal, const fl
                                  const float* rays_o, const float* rays_d, int R, int S, const float* inv_s,
                                  float sample_dist, float cos_anneal, const float* bg, int bg_mode, float* color,
                                  float* extra, float* weights, float* cdf, float* mid_z, float* inside, float* eik,
-                                 void* stream) {
+                                 float* wstat, float* nsum, void* stream) {
   if (S > MAXS || S < 1) { avc_set_error("avc_composite_fwd: 1 <= S <= 256"); return 1; }
   if (R <= 0) return 0;
   hipLaunchKernelGGL(composite_fwd_kernel, dim3((R + RPB - 1) / RPB), dim3(256), 0, (hipStream_t)stream, sdf, normal, rgb,
                      z, rays_o, rays_d, R, S, inv_s, sample_dist, cos_anneal, bg, bg_mode, color, extra, weights, cdf,
-                     mid_z, inside, eik);
+                     mid_z, inside, eik, wstat, nsum);
   return avc_check_launch("avc_composite_fwd");
 }
 
@@ -265,7 +278,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     const float* __restrict__ z, const float* __restrict__ rays_o, const float* __restrict__ rays_d, int R, int S,
     const float* __restrict__ inv_s_p, float sample_dist, float car, const float* __restrict__ bg, int bg_mode,
     const float* __restrict__ d_color, const float* __restrict__ d_extra, const float* __restrict__ d_weights,
-    const float* __restrict__ d_normal_up, const float* __restrict__ eik_scale_p, float* __restrict__ d_sdf,
+    const float* __restrict__ d_normal_up, const float* __restrict__ d_wsum, const float* __restrict__ d_nsum,
+    const float* __restrict__ eik_scale_p, float* __restrict__ d_sdf,
     float* __restrict__ d_normal, float* __restrict__ d_rgb, float* __restrict__ d_inv_s) {
   __shared__ float sT[RPB][MAXS], sA[RPB][MAXS], sW[RPB][MAXS], sS[RPB][MAXS];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -283,6 +297,9 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
   else if (bg_mode == 2) { b0 = b1 = b2 = bg[ray]; }
   const float dc0 = d_color[3 * ray], dc1 = d_color[3 * ray + 1], dc2 = d_color[3 * ray + 2];
   const float de0 = d_extra[3 * ray], de1 = d_extra[3 * ray + 1], de2 = d_extra[3 * ray + 2];
+  // upstream gradients of the per-ray reductions of the weights (sum_i w_i and sum_i w_i n_i: avc_composite_fwd's wstat / nsum)
+  const float dws = d_wsum ? d_wsum[ray] : 0.f;
+  const float dn0 = d_nsum ? d_nsum[3 * ray] : 0.f, dn1 = d_nsum ? d_nsum[3 * ray + 1] : 0.f, dn2 = d_nsum ? d_nsum[3 * ray + 2] : 0.f;
   for (int i = lane; i < S; i += 64) {
     const float zv = z[base + i];
     const float dist = (i + 1 < S) ? z[base + i + 1] - zv : sample_dist;
@@ -292,7 +309,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     T[i] = 1.f - v.alpha + 1e-7f;
     const float* r = rgb + 6 * (base + i);
     WB[i] = dc0 * r[0] + dc1 * r[1] + dc2 * r[2] + de0 * (r[3] - b0) + de1 * (r[4] - b1) + de2 * (r[5] - b2) +
-            d_weights[base + i];
+            (d_weights ? d_weights[base + i] : 0.f) + dws + dn0 * nx + dn1 * ny + dn2 * nz;
   }
   __syncthreads();
   const int per = (S + 63) / 64;
@@ -350,6 +367,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     const float d_c = d_ic * (0.5f * (1.f - car) * ((-0.5f * v.c + 0.5f) > 0.f ? 1.f : 0.f) + car * ((-v.c) > 0.f ? 1.f : 0.f));
     float gx = d_c * dx, gy = d_c * dy, gz = d_c * dz;
     if (d_normal_up) { gx += d_normal_up[3 * (base + i)]; gy += d_normal_up[3 * (base + i) + 1]; gz += d_normal_up[3 * (base + i) + 2]; }
+    gx += wv * dn0; gy += wv * dn1; gz += wv * dn2;
     if (pn < 1.2f) {
       const float gn = sqrtf(nx * nx + ny * ny + nz * nz);
       const float k = eik_scale * 2.f * (gn - 1.f) / gn;
@@ -365,12 +383,12 @@ extern "C" int avc_composite_bwd(const float* sdf, const float* normal, const fl
                                  const float* rays_o, const float* rays_d, int R, int S, const float* inv_s,
                                  float sample_dist, float cos_anneal, const float* bg, int bg_mode,
                                  const float* d_color, const float* d_extra, const float* d_weights,
-                                 const float* d_normal_up, const float* eik_scale, float* d_sdf, float* d_normal,
-                                 float* d_rgb, float* d_inv_s, void* stream) {
+                                 const float* d_normal_up, const float* d_wsum, const float* d_nsum, const float* eik_scale,
+                                 float* d_sdf, float* d_normal, float* d_rgb, float* d_inv_s, void* stream) {
   if (S > MAXS || S < 1) { avc_set_error("avc_composite_bwd: 1 <= S <= 256"); return 1; }
   if (R <= 0) return 0;
   hipLaunchKernelGGL(composite_bwd_kernel, dim3((R + RPB - 1) / RPB), dim3(256), 0, (hipStream_t)stream, sdf, normal, rgb,
                      z, rays_o, rays_d, R, S, inv_s, sample_dist, cos_anneal, bg, bg_mode, d_color, d_extra, d_weights,
-                     d_normal_up, eik_scale, d_sdf, d_normal, d_rgb, d_inv_s);
+                     d_normal_up, d_wsum, d_nsum, eik_scale, d_sdf, d_normal, d_rgb, d_inv_s);
   return avc_check_launch("avc_composite_bwd");
 }

@@ -54,8 +54,10 @@ class Packed:
         self.dl = dl
 
 
-def flatten_dense(sdf_net, col_net, spec: PK.NetSpec) -> torch.Tensor:
-    """Flat differentiable vector of every dense weight in packing.param_shapes order."""
+def flatten_dense_torch(sdf_net, col_net, spec: PK.NetSpec) -> torch.Tensor:
+    """Flat differentiable vector of every dense weight in packing.param_shapes order as plain torch expressions (weight norm
+    by `fields.dense_weight`): the host-logic statement of flatten_dense, used by the CPU tests and as the parity reference of
+    the fused kernel."""
     parts = []
     for W, b in sdf_net.dense():
         parts += [W.reshape(-1), b.reshape(-1)]
@@ -69,11 +71,87 @@ def flatten_dense(sdf_net, col_net, spec: PK.NetSpec) -> torch.Tensor:
     return torch.cat(parts)
 
 
+def _dense_layers(sdf_net, col_net, lay):
+    """[(linear module, flat offset of W, flat offset of b)] in packing.param_shapes order; the stacked 6 x H colour head is two
+    linears (lin_last rows 0..2, extra_lin rows 3..5) writing into the same W / b blocks"""
+    out = []
+    n_sdf = sdf_net.num_layers - 1
+    for l in range(n_sdf):
+        out.append((getattr(sdf_net, "lin%d" % l), lay.pbase["sdf.W%d" % l], lay.pbase["sdf.b%d" % l]))
+    if col_net is not None:
+        nh = col_net.num_layers - 2
+        for l in range(nh):
+            out.append((getattr(col_net, "lin%d" % l), lay.pbase["col.W%d" % l], lay.pbase["col.b%d" % l]))
+        last = getattr(col_net, "lin%d" % nh)
+        H = last.weight_v.shape[1] if hasattr(last, "weight_v") else last.weight.shape[1]
+        out.append((last, lay.pbase["col.Wh"], lay.pbase["col.bh"]))
+        if col_net.extra_color:
+            out.append((col_net.extra_lin, lay.pbase["col.Wh"] + 3 * H, lay.pbase["col.bh"] + 3))
+    return out
+
+
+class DenseParamsFn(torch.autograd.Function):
+    """every dense weight (weight norm resolved: W = g v / ||v||_row, fields.py:65-66) and bias in ONE flat vector, one launch
+    forward and one backward (csrc/avc_params.hip) instead of ~4 + ~10 torch kernels per weight-normed linear"""
+
+    @staticmethod
+    def forward(ctx, meta, *tensors):
+        lay, offs = meta
+        n = len(offs)
+        dev = tensors[0].device
+        flat = torch.zeros(lay.nparam, device=dev, dtype=torch.float32)
+        vs, gs, bs = tensors[0::3], tensors[1::3], tensors[2::3]
+        PA = ctypes.c_void_p * n
+        arr = lambda ts: PA(*[(t.data_ptr() if t.numel() else None) for t in ts])
+        ctx.rows = (ctypes.c_int * n)(*[v.shape[0] for v in vs])
+        ctx.cols = (ctypes.c_int * n)(*[v.shape[1] for v in vs])
+        ctx.w_off = (ctypes.c_long * n)(*[o[0] for o in offs])
+        ctx.b_off = (ctypes.c_long * n)(*[o[1] for o in offs])
+        ctx.n = n
+        lib = L.load()
+        assert all(t.is_contiguous() and t.dtype == torch.float32 for t in tensors)
+        L.check(lib.avc_dense_params_fwd(n, arr(vs), arr(gs), arr(bs), ctx.rows, ctx.cols, ctx.w_off, ctx.b_off, L.ptr(flat), L.stream()),
+                "avc_dense_params_fwd")
+        ctx.save_for_backward(*tensors)
+        return flat
+
+    @staticmethod
+    def backward(ctx, dflat):
+        tensors = ctx.saved_tensors
+        n = ctx.n
+        vs, gs, bs = tensors[0::3], tensors[1::3], tensors[2::3]
+        dflat = dflat.contiguous().float()
+        outs = [torch.empty_like(t) for t in tensors]
+        PA = ctypes.c_void_p * n
+        arr = lambda ts: PA(*[(t.data_ptr() if t.numel() else None) for t in ts])
+        L.check(L.load().avc_dense_params_bwd(n, arr(vs), arr(gs), arr(outs[0::3]), arr(outs[1::3]), arr(outs[2::3]), ctx.rows, ctx.cols,
+                                              ctx.w_off, ctx.b_off, L.ptr(dflat), L.stream()), "avc_dense_params_bwd")
+        return (None,) + tuple(o if t.numel() else None for o, t in zip(outs, tensors))
+
+
+def flatten_dense(sdf_net, col_net, spec: PK.NetSpec) -> torch.Tensor:
+    """Flat differentiable vector of every dense weight in packing.param_shapes order (the fused kernel on the device; modules on
+    the CPU -- host-logic tests only -- go through the torch statement)."""
+    p0 = next(sdf_net.parameters())
+    if p0.device.type != "cuda":
+        return flatten_dense_torch(sdf_net, col_net, spec)
+    lay = PK.layout_for(spec)
+    tensors, offs = [], []
+    empty = p0.new_zeros(0)
+    for lin, w_off, b_off in _dense_layers(sdf_net, col_net, lay):
+        if hasattr(lin, "weight_g"):
+            tensors += [lin.weight_v, lin.weight_g, lin.bias if lin.bias is not None else empty]
+        else:
+            tensors += [lin.weight, empty, lin.bias if lin.bias is not None else empty]
+        offs.append((int(w_off), int(b_off)))
+    return DenseParamsFn.apply((lay, offs), *tensors)
+
+
 class Engine:
     _by_net = weakref.WeakKeyDictionary()
     PROFILE = False               # bench.py: record (name, points, start_event, end_event) per kernel launch group
     prof_events = []
-    WG_BLOCKS_PER_SPLIT = 1024    # split-K of the weight-gradient launch: blocks per workgroup (nsplit = blocks / this, 1..256; one slab of
+    WG_BLOCKS_PER_SPLIT = int(os.environ.get("AVC_WG_BLOCKS_PER_SPLIT", "1024"))    # split-K of the weight-gradient launch: blocks per workgroup (nsplit = blocks / this, 1..256; one slab of
                                   # 131072 blocks = 128 splits x 13 pairs = 1664 workgroups over 256 CUs)
     MAX_FWD_WAVES = 2048          # persistent grid of avc_render_points_fwd: 256 CUs x one 8-wave workgroup
     MAX_BWD_WAVES = 2048          # 256 CUs x one 8-wave workgroup
@@ -268,6 +346,7 @@ class Engine:
         return out
 
     def composite_fwd(self, sdf, nrm, rgb, z, rays_o, rays_d, inv_s, sample_dist, cos_anneal, bg, bg_mode):
+        """-> color, extra, weights, cdf, mid_z, inside, eik, wstat [R,2] = (sum_i w_i, max_i w_i), nsum [R,3] = sum_i w_i n_i"""
         R, S = z.shape
         dev, f32 = self.device, torch.float32
         color = torch.empty(R, 3, device=dev, dtype=f32)
@@ -277,14 +356,16 @@ class Engine:
         mid_z = torch.empty(R, S, device=dev, dtype=f32)
         inside = torch.empty(R, S, device=dev, dtype=f32)
         eik = torch.empty(R, 2, device=dev, dtype=f32)
+        wstat = torch.empty(R, 2, device=dev, dtype=f32)
+        nsum = torch.empty(R, 3, device=dev, dtype=f32)
         L.check(self.lib.avc_composite_fwd(L.ptr(sdf), L.ptr(nrm), L.ptr(rgb), L.ptr(z), L.ptr(rays_o), L.ptr(rays_d), R, S,
                                            L.ptr(inv_s), float(sample_dist), float(cos_anneal), L.ptr(bg), bg_mode,
                                            L.ptr(color), L.ptr(extra), L.ptr(weights), L.ptr(cdf), L.ptr(mid_z),
-                                           L.ptr(inside), L.ptr(eik), L.stream()), "avc_composite_fwd")
-        return color, extra, weights, cdf, mid_z, inside, eik
+                                           L.ptr(inside), L.ptr(eik), L.ptr(wstat), L.ptr(nsum), L.stream()), "avc_composite_fwd")
+        return color, extra, weights, cdf, mid_z, inside, eik, wstat, nsum
 
     def composite_bwd(self, sdf, nrm, rgb, z, rays_o, rays_d, inv_s, sample_dist, cos_anneal, bg, bg_mode, d_color,
-                      d_extra, d_w, d_n_up, eik_scale):
+                      d_extra, d_w, d_n_up, eik_scale, d_wsum=None, d_nsum=None):
         R, S = z.shape
         dev, f32 = self.device, torch.float32
         d_sdf = torch.empty(R, S, device=dev, dtype=f32)
@@ -293,8 +374,8 @@ class Engine:
         d_inv = torch.empty(R, device=dev, dtype=f32)
         L.check(self.lib.avc_composite_bwd(L.ptr(sdf), L.ptr(nrm), L.ptr(rgb), L.ptr(z), L.ptr(rays_o), L.ptr(rays_d), R, S,
                                            L.ptr(inv_s), float(sample_dist), float(cos_anneal), L.ptr(bg), bg_mode,
-                                           L.ptr(d_color), L.ptr(d_extra), L.ptr(d_w), L.ptr(d_n_up), L.ptr(eik_scale),
-                                           L.ptr(d_sdf), L.ptr(d_n), L.ptr(d_rgb), L.ptr(d_inv), L.stream()),
+                                           L.ptr(d_color), L.ptr(d_extra), L.ptr(d_w), L.ptr(d_n_up), L.ptr(d_wsum), L.ptr(d_nsum),
+                                           L.ptr(eik_scale), L.ptr(d_sdf), L.ptr(d_n), L.ptr(d_rgb), L.ptr(d_inv), L.stream()),
                 "avc_composite_bwd")
         return d_sdf, d_n, d_rgb, d_inv
 
@@ -377,19 +458,23 @@ class RenderCoreFn(torch.autograd.Function):
             ctx.panel_token = eng._panel_owner = object()
         else:
             sdf, nrm, rgb = eng.points_fwd(pk, rays_o, rays_d, z_vals, sample_dist)
-        color, extra, weights, cdf, mid_z, inside, eik = eng.composite_fwd(
+        color, extra, weights, cdf, mid_z, inside, eik, wstat, nsum = eng.composite_fwd(
             sdf, nrm, rgb, z_vals, rays_o, rays_d, inv_s_d, sample_dist, cos_anneal, bg, bg_mode)
+        wsum, wmax = wstat[:, 0:1].contiguous(), wstat[:, 1:2].contiguous()
         eik_den = eik[:, 1].sum() + 1e-5
         gerr = eik[:, 0].sum() / eik_den
         ctx.eng, ctx.pk = eng, pk
         ctx.consts = (sample_dist, cos_anneal, bg_mode)
         ctx.save_for_backward(rays_o, rays_d, z_vals, sdf, nrm, rgb, inv_s_d, eik_den, bg if bg is not None else inv_s_d)
         ctx.has_bg = bg is not None
-        ctx.mark_non_differentiable(cdf, mid_z, inside, sdf)
-        return color, extra, weights, nrm, gerr, cdf, mid_z, inside, sdf
+        ctx.mark_non_differentiable(cdf, mid_z, inside, sdf, wmax)
+        # wsum = sum_i w_i, wmax = max_i w_i, nsum = sum_i w_i n_i: the per-ray reductions render() and the shading of main.py:428
+        # take of the weights, out of the compositing kernel's own registers (and differentiable through its reverse scan)
+        return color, extra, weights, nrm, gerr, cdf, mid_z, inside, sdf, wsum, wmax, nsum
 
     @staticmethod
-    def backward(ctx, d_color, d_extra, d_weights, d_nrm, d_gerr, *unused):
+    def backward(ctx, d_color, d_extra, d_weights, d_nrm, d_gerr, d_cdf=None, d_midz=None, d_inside=None, d_sdf_out=None,
+                 d_wsum=None, d_wmax=None, d_nsum=None):
         eng, pk = ctx.eng, ctx.pk
         rays_o, rays_d, z_vals, sdf, nrm, rgb, inv_s_d, eik_den, bg = ctx.saved_tensors
         if not ctx.has_bg:
@@ -399,12 +484,15 @@ class RenderCoreFn(torch.autograd.Function):
         zeros = lambda *s: torch.zeros(*s, device=z_vals.device, dtype=torch.float32)
         d_color = d_color.contiguous().float() if d_color is not None else zeros(R, 3)
         d_extra = d_extra.contiguous().float() if d_extra is not None else zeros(R, 3)
-        d_weights = d_weights.contiguous().float() if d_weights is not None else zeros(R, S)
+        d_weights = d_weights.contiguous().float() if d_weights is not None else None
         d_nrm = d_nrm.contiguous().float() if d_nrm is not None else None
+        d_wsum = d_wsum.contiguous().float().reshape(R) if d_wsum is not None else None
+        d_nsum = d_nsum.contiguous().float() if d_nsum is not None else None
         d_gerr = d_gerr if d_gerr is not None else zeros(())
         eik_scale = (d_gerr.float() / eik_den).reshape(1).contiguous()
         d_sdf, d_n, d_rgb, d_inv = eng.composite_bwd(sdf, nrm, rgb, z_vals, rays_o, rays_d, inv_s_d, sample_dist,
-                                                     cos_anneal, bg, bg_mode, d_color, d_extra, d_weights, d_nrm, eik_scale)
+                                                     cos_anneal, bg, bg_mode, d_color, d_extra, d_weights, d_nrm, eik_scale,
+                                                     d_wsum, d_nsum)
         valid = ctx.panel_token is not None and eng._panel_owner is ctx.panel_token
         grad = eng.points_bwd(pk, rays_o, rays_d, z_vals, sample_dist, d_sdf, d_n, d_rgb, rgb, panels_valid=valid)
         return grad, d_inv.sum().reshape(1), None, None, None, None, None, None, None, None

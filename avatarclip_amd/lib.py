@@ -19,9 +19,9 @@ _SIGS = {
     "avc_upsample_step": (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, P, P, P, P, P]),
     "avc_render_points_fwd": (c_int, [c_int, P, P, P, P, c_int, c_int, c_float, c_long, P, P, P, P, P, P, c_long, P, P]),
     "avc_fwd_scratch_bytes_per_wave": (c_long, [c_int]),
-    "avc_composite_fwd": (c_int, [P, P, P, P, P, P, c_int, c_int, P, c_float, c_float, P, c_int, P, P, P, P, P, P, P, P]),
+    "avc_composite_fwd": (c_int, [P, P, P, P, P, P, c_int, c_int, P, c_float, c_float, P, c_int, P, P, P, P, P, P, P, P, P, P]),
     "avc_composite_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, P, c_float, c_float, P, c_int, P, P, P, P, P, P, P,
-                                  P, P, P]),
+                                  P, P, P, P, P]),
     "avc_render_points_fwd_train": (c_int, [c_int, P, P, P, P, c_int, c_int, c_float, c_long, P, P, P, P, P, P, c_long, P, P, P]),
     "avc_fwd_panel_tiles": (c_int, [c_int]),
     "avc_grad_panel_tiles": (c_int, [c_int]),
@@ -37,6 +37,8 @@ _SIGS = {
     "avc_vit_attention_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "avc_probe_mfma": (c_int, [P, P, P, P, P, P, P]),
     "avc_rasterize_faces": (c_int, [P, P, c_int, c_int, c_float, c_float, P, P]),
+    "avc_dense_params_fwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P]),
+    "avc_dense_params_bwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P]),
     "avc_weight_grad_all": (c_int, [P, c_int, P, c_int, c_int, P, c_long, P, P, c_int, c_int, c_int, P]),
 }
 _OPTIONAL = {}

@@ -13,6 +13,13 @@ import torch
 from .engine import Engine, RenderCoreFn, flatten_dense
 
 
+class RenderOut(dict):
+    """the reference's 11-key result dict (renderer.py:385-397) plus ONE attribute that is not a key: `weighted_normals` [R,3] =
+    (gradients * weights[:, :, None]).sum(dim=1), the first line of the shading of main.py:428, which the compositing kernel
+    has in registers anyway (differentiable like the tensors of the dict; Runner.shade_and_scatter takes it when it is there)"""
+    weighted_normals = None
+
+
 class NeuSRenderer:
     def __init__(self, nerf, sdf_network, deviation_network, color_network, n_samples, n_importance, n_outside,
                  up_sample_steps, perturb, extra_color=False):
@@ -82,15 +89,15 @@ class NeuSRenderer:
                 bg, bg_mode = bgt.reshape(R).contiguous(), 2
             else:
                 raise ValueError("background_rgb must be [1,3] or [R,1] (main.py:387-415)")
-        color, extra, weights, gradients, gerr, cdf, mid_z, inside, sdf = RenderCoreFn.apply(
+        color, extra, weights, gradients, gerr, cdf, mid_z, inside, sdf, wsum, wmax, nsum = RenderCoreFn.apply(
             flatP, inv_s, eng, rays_o, rays_d, z_vals, float(sample_dist), float(cos_anneal_ratio), bg, bg_mode)
         if not self.extra_color:
             extra = None
             if background_rgb is not None:  # renderer.py:280-281
-                color = color + background_rgb.to(color.device) * (1.0 - weights.sum(dim=-1, keepdim=True))
+                color = color + background_rgb.to(color.device) * (1.0 - wsum)
         return {"color": color, "extra_color": extra, "sdf": sdf.reshape(-1, 1), "gradients": gradients,
                 "s_val": 1.0 / inv_s.detach().reshape(1, 1), "mid_z_vals": mid_z, "weights": weights, "cdf": cdf,
-                "gradient_error": gerr, "inside_sphere": inside}
+                "gradient_error": gerr, "inside_sphere": inside, "weight_sum": wsum, "weight_max": wmax, "weighted_normals": nsum}
 
     def render(self, rays_o, rays_d, near, far, perturb_overwrite=-1, background_rgb=None, cos_anneal_ratio=0.0,
                jitter=None, z_vals=None):
@@ -108,19 +115,21 @@ class NeuSRenderer:
         ret = self.render_core(rays_o, rays_d, z_vals, sample_dist, background_rgb, cos_anneal_ratio, flatP)
         weights = ret["weights"]
         R, S = weights.shape
-        return {
+        out = RenderOut({
             "color_fine": ret["color"],
             "extra_color_fine": ret["extra_color"],
             "s_val": ret["s_val"].expand(R, 1),
             "cdf_fine": ret["cdf"],
-            "weight_sum": weights.sum(dim=-1, keepdim=True),
-            "weight_max": torch.max(weights, dim=-1, keepdim=True)[0],
+            "weight_sum": ret["weight_sum"],          # = weights.sum(-1, keepdim=True) / torch.max(weights, -1, keepdim=True)[0]
+            "weight_max": ret["weight_max"],          #   (renderer.py:391-392), reduced inside the compositing kernel
             "gradients": ret["gradients"],
             "weights": weights,
             "mid_z_vals": ret["mid_z_vals"],
             "gradient_error": ret["gradient_error"],
             "inside_sphere": ret["inside_sphere"],
-        }
+        })
+        out.weighted_normals = ret["weighted_normals"]
+        return out
 
     def extract_geometry(self, bound_min, bound_max, resolution, threshold=0.0):
         """renderer.py:399-404: marching cubes of -sdf at `threshold` on a resolution^3 grid -> (vertices, triangles)"""

@@ -161,7 +161,8 @@ class Runner:
             parallel.broadcast_params(params_to_train)
             self.seed_data_rngs()
         self.grad_bucket = parallel.GradBucket(params_to_train) if parallel.is_on() else None
-        self.optimizer = torch.optim.Adam(params_to_train, lr=self.learning_rate)
+        # main.py:145; fused = the same update in ONE launch for all 28 tensors instead of a dozen multi-tensor launches
+        self.optimizer = torch.optim.Adam(params_to_train, lr=self.learning_rate, fused=(self.device.type == "cuda"))
         self.renderer = NeuSRenderer(self.nerf_outside, self.sdf_network, self.deviation_network, self.color_network,
                                      **self.conf["model.neus_renderer"])
         pretrain_pth = c.get_string("train.pretrain", default=None)
@@ -431,7 +432,9 @@ class Runner:
         extra_color_fine = render_out["extra_color_fine"]
         texture_shading = rand_shading_rgb = None
         if self.add_no_texture or self.texture_cast_light:
-            normals = (render_out["gradients"] * render_out["weights"][:, :, None]).sum(dim=1)
+            normals = getattr(render_out, "weighted_normals", None)      # the same sum out of the compositing kernel (renderer.RenderOut)
+            if normals is None:
+                normals = (render_out["gradients"] * render_out["weights"][:, :, None]).sum(dim=1)
             normals = normals / (torch.norm(normals, dim=-1, keepdim=True) + 1e-7)
             if light is None:
                 light_dir = sphere_coord(view.theta + np.random.uniform(-np.pi / 4, np.pi / 4),

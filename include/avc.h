@@ -56,20 +56,22 @@ long avc_fwd_scratch_bytes_per_wave(int net);
 /* NeuS alpha + compositing of render_core (renderer.py:234-286), one wavefront per ray.
  * bg_mode 0: none, 1: bg[3] shared, 2: bg[R] grey per ray (main.py:387-415); background is composited into
  * `extra` only (renderer.py:277-281).  Outputs: color[R,3], extra[R,3], weights[R,S], cdf[R,S], mid_z[R,S],
- * inside[R,S], eik[R,2] = per-ray (sum relax*(|n|-1)^2, sum relax). */
+ * inside[R,S], eik[R,2] = per-ray (sum relax*(|n|-1)^2, sum relax); optional (NULL = skip) per-ray reductions of the weights
+ * that the callers of render() take next: wstat[R,2] = (sum_i w_i, max_i w_i) (renderer.py:391-392 weight_sum / weight_max)
+ * and nsum[R,3] = sum_i w_i n_i (the shading normal of main.py:428 before its normalisation). */
 int avc_composite_fwd(const float* sdf, const float* normal, const float* rgb, const float* z, const float* rays_o,
                       const float* rays_d, int R, int S, const float* inv_s /* device scalar */, float sample_dist,
                       float cos_anneal, const float* bg, int bg_mode, float* color, float* extra, float* weights,
-                      float* cdf, float* mid_z, float* inside, float* eik, void* stream);
+                      float* cdf, float* mid_z, float* inside, float* eik, float* wstat, float* nsum, void* stream);
 
-/* Reverse of avc_composite_fwd.  Upstream: d_color[R,3], d_extra[R,3], d_weights[R,S], d_normal_up[R,S,3] (may be
- * NULL), eik_scale = d(loss)/d(eik) / (sum relax + 1e-5) (device scalar).  Outputs: d_sdf[R,S], d_normal[R,S,3],
- * d_rgb[R,S,6], d_inv_s[R] (per-ray partial of d loss / d inv_s). */
+/* Reverse of avc_composite_fwd.  Upstream: d_color[R,3], d_extra[R,3], d_weights[R,S] (may be NULL), d_normal_up[R,S,3] (may
+ * be NULL), d_wsum[R] / d_nsum[R,3] = gradients of wstat[:,0] / nsum (may be NULL), eik_scale = d(loss)/d(eik) / (sum relax +
+ * 1e-5) (device scalar).  Outputs: d_sdf[R,S], d_normal[R,S,3], d_rgb[R,S,6], d_inv_s[R] (per-ray partial of d loss / d inv_s). */
 int avc_composite_bwd(const float* sdf, const float* normal, const float* rgb, const float* z, const float* rays_o,
                       const float* rays_d, int R, int S, const float* inv_s, float sample_dist, float cos_anneal,
                       const float* bg, int bg_mode, const float* d_color, const float* d_extra,
-                      const float* d_weights, const float* d_normal_up, const float* eik_scale, float* d_sdf,
-                      float* d_normal, float* d_rgb, float* d_inv_s, void* stream);
+                      const float* d_weights, const float* d_normal_up, const float* d_wsum, const float* d_nsum,
+                      const float* eik_scale, float* d_sdf, float* d_normal, float* d_rgb, float* d_inv_s, void* stream);
 
 /* The differentiable forward of render_core (renderer.py:221-232, once per iteration as in the reference): the same outputs
  * as avc_render_points_fwd, plus everything the backward pass and the weight-gradient products need from the forward pass,
@@ -114,6 +116,16 @@ int avc_render_points_bwd(int net, const float* pts, const float* rays_o, const 
 int avc_weight_grad_all(const void* fpanels, int ftiles, const void* gpanels, int gtiles, int npairs,
                         const int* pairs /* host */, long nblk, float* partial, float* bias_partial, int nsplit,
                         int out_stride, int bias_stride, void* stream);
+
+/* Dense-parameter assembly of one optimisation step: W_l = g_l * v_l / ||v_l||_row (nn.utils.weight_norm, fields.py:65-66,139-143;
+ * g[l] == NULL: the plain weight) and the biases of `n` linears written into the flat dense vector `flat` at w_off[l] (row-major
+ * [rows, cols]) / b_off[l] (floats), and the backward of that map: dflat -> dv[l], dg[l], db[l] (b[l] / db[l] may be NULL).
+ * The arrays of pointers / shapes are HOST arrays (n <= 16). */
+int avc_dense_params_fwd(int n, const void* const* v, const void* const* g, const void* const* b, const int* rows,
+                         const int* cols, const long* w_off, const long* b_off, float* flat, void* stream);
+int avc_dense_params_bwd(int n, const void* const* v, const void* const* g, void* const* dv, void* const* dg, void* const* db,
+                         const int* rows, const int* cols, const long* w_off, const long* b_off, const float* dflat,
+                         void* stream);
 
 /* ---- mesh extraction (Runner.validate_mesh, main.py:850-919; renderer.py:10-36; mcubes.marching_cubes) ----
  * Marching cubes over u[nx][ny][nz] (row-major, the reference's extract_fields layout) at iso level `iso`, inside = u > iso,

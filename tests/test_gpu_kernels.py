@@ -168,7 +168,10 @@ def test_composite_forward_backward_fp32():
         D = lambda t: None if t is None else t.to(dev).contiguous()
         out = eng.composite_fwd(D(sdf), D(n), D(rgb), D(z), D(ro), D(rd), D(inv_s), sd, car, D(bg), bg_mode)
         torch.cuda.synchronize()
-        color, extra, w, cdf, mid_z, inside, eik = [o.cpu() for o in out]
+        color, extra, w, cdf, mid_z, inside, eik, wstat, nsum = [o.cpu() for o in out]
+        # the per-ray reductions of the weights the kernel hands out beside them (renderer.py:391-392, main.py:428)
+        assert torch.allclose(wstat[:, 0], w.sum(-1), atol=1e-5) and torch.allclose(wstat[:, 1], w.max(-1)[0], atol=1e-7)
+        assert torch.allclose(nsum, (n * w[..., None]).sum(1), atol=1e-5)
         assert torch.allclose(color.double(), cf["color"], atol=2e-5)
         assert torch.allclose(extra.double(), cf["extra"], atol=2e-5)
         assert torch.allclose(w.double(), cf["w"], atol=2e-5)
@@ -177,13 +180,21 @@ def test_composite_forward_backward_fp32():
         d_color, d_extra = torch.randn(R, 3, generator=g), torch.randn(R, 3, generator=g)
         d_w, d_n_up = torch.randn(R, S, generator=g), torch.randn(R, S, 3, generator=g) * 0.1
         d_eik = torch.tensor(0.7)
+        # gradients of the fused reductions: d/dw of sum_i w_i and of sum_i w_i n_i fold into d_w, the latter also into d_n
+        d_wsum, d_nsum = torch.randn(R, generator=g), torch.randn(R, 3, generator=g) * 0.1
+        d_w_tot = d_w + d_wsum[:, None] + (n * d_nsum[:, None, :]).sum(-1)
+        d_n_tot = d_n_up + cf["w"].float()[..., None] * d_nsum[:, None, :]
         cb = A.composite_backward(cf, sdf.double(), n.double(), rgb.double(), rd.double(), inv_s.double(), car,
                                   None if bgr is None else (bgr.double() if bg_mode == 1 else bgr.double().expand(R, 3)),
-                                  d_color.double(), d_extra.double(), d_w.double(), d_n_up.double(), d_eik.double()) \
+                                  d_color.double(), d_extra.double(), d_w_tot.double(), d_n_tot.double(), d_eik.double()) \
             if bg_mode != 2 else None
         eik_scale = (d_eik / cf["eik_den"].float()).reshape(1)
         bo = eng.composite_bwd(D(sdf), D(n), D(rgb), D(z), D(ro), D(rd), D(inv_s), sd, car, D(bg), bg_mode, D(d_color),
-                               D(d_extra), D(d_w), D(d_n_up), D(eik_scale))
+                               D(d_extra), D(d_w), D(d_n_up), D(eik_scale), D(d_wsum), D(d_nsum))
+        b2 = eng.composite_bwd(D(sdf), D(n), D(rgb), D(z), D(ro), D(rd), D(inv_s), sd, car, D(bg), bg_mode, D(d_color),
+                               D(d_extra), D(d_w_tot), D(d_n_tot), D(eik_scale))      # the same through the per-sample inputs
+        for x, y in zip(bo, b2):
+            assert relerr(x.cpu().double(), y.cpu().double()) < 1e-5
         torch.cuda.synchronize()
         if cb is not None:
             d_sdf, d_n, d_rgb, d_inv = [o.cpu().double() for o in bo]
@@ -272,3 +283,35 @@ def test_full_sampling_chain_close_to_reference(name):
     print(name, "color max", e.max().item(), "mean", e.mean().item(), "extra max", e2.max().item(), "mean", e2.mean().item())
     assert e.mean() < 3e-3 and e2.mean() < 3e-3
     assert (e.max(dim=-1)[0] > 5e-2).float().mean() < 0.03
+
+
+@gpu
+@pytest.mark.parametrize("extra_color", [True, False])
+def test_fused_dense_parameter_assembly_matches_torch_weight_norm(extra_color):
+    """csrc/avc_params.hip (weight norm of every linear + flattening, fields.py:65-66,139-143) forward and backward against the plain
+    torch expressions `fields.dense_weight` + cat, fp32 both: values to 1e-6, gradients to 1e-5 relative"""
+    from avatarclip_amd import fields, packing as PK
+    from avatarclip_amd.engine import flatten_dense, flatten_dense_torch
+    dev = torch.device("cuda")
+    torch.manual_seed(5)
+    sdf = fields.SDFNetwork(d_out=257, d_in=3, d_hidden=256, n_layers=4, skip_in=[4], multires=6, bias=0.5, scale=1.0,
+                            geometric_init=True, weight_norm=True).to(dev)
+    col = fields.RenderingNetwork(d_feature=256, mode="no_view_dir", d_in=6, d_out=3, d_hidden=256, n_layers=2,
+                                  weight_norm=True, multires_view=0, squeeze_out=True, extra_color=extra_color).to(dev)
+    with torch.no_grad():
+        for p in list(sdf.parameters()) + list(col.parameters()):
+            p.add_(torch.randn_like(p) * 0.05)
+    params = list(sdf.parameters()) + list(col.parameters())
+    a = flatten_dense(sdf, col, PK.FULL)
+    b = flatten_dense_torch(sdf, col, PK.FULL)
+    assert a.shape == b.shape and (a - b).abs().max().item() < 1e-6
+    w = torch.randn_like(a)
+    ga = torch.autograd.grad((a * w).sum(), params, allow_unused=True)
+    gb = torch.autograd.grad((b * w).sum(), params, allow_unused=True)
+    for p, x, y in zip(params, ga, gb):
+        assert (x is None) == (y is None)
+        if x is not None:
+            assert (x - y).norm() <= 1e-5 * (y.norm() + 1e-6), ((x - y).abs().max().item(), y.abs().max().item())
+    # the SDF-only path (no colour net): zeros behind the SDF block
+    c = flatten_dense(sdf, None, PK.FULL)
+    assert torch.equal(c[: a.numel()][c != 0], a[c != 0]) and c.numel() == a.numel()

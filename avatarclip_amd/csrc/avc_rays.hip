@@ -8,6 +8,10 @@
 
 #define MAXS 256          // max samples per ray handled by these kernels
 #define RPB 4             // rays (wavefronts) per 256-thread block
+// Every wavefront works on its own ray in its own LDS rows: the phases of a ray need ordering only WITHIN the wavefront.  LDS
+// operations of one wavefront complete in issue order, so draining its LDS counter (a compiler barrier as well) is all the
+// synchronisation there is -- a workgroup barrier here made the four rays of a block wait for each other nine times per step.
+#define WAVE_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 
 __device__ __forceinline__ float wave_incl_scan_mul(float v, int lane) {
 #pragma unroll
@@ -64,18 +68,18 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
                                                        int* __restrict__ slot_new) {
   __shared__ float sz[RPB][MAXS], ss[RPB][MAXS], sa[RPB][MAXS], sc[RPB][MAXS], sn[RPB][64];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // no early return: every wave of the block must reach the __syncthreads() below
+  // (wavefronts past the last ray redo ray R - 1 without storing)
   const bool active = blockIdx.x * RPB + w < R;
   const int ray = active ? blockIdx.x * RPB + w : R - 1;
   float* Z = sz[w]; float* Sd = ss[w]; float* A = sa[w]; float* C = sc[w]; float* NZ = sn[w];
   const float ox = rays_o[3 * ray], oy = rays_o[3 * ray + 1], oz = rays_o[3 * ray + 2];
   const float dx = rays_d[3 * ray], dy = rays_d[3 * ray + 1], dz = rays_d[3 * ray + 2];
   for (int i = lane; i < n; i += 64) { Z[i] = z_in[(long)ray * n + i]; Sd[i] = sdf_in[(long)ray * n + i]; }
-  __builtin_amdgcn_s_waitcnt(0); __syncthreads();
+  WAVE_SYNC();
   const int nm1 = n - 1;
   // raw cos of every section (renderer.py:143)
   for (int i = lane; i < nm1; i += 64) C[i] = (Sd[i + 1] - Sd[i]) / (Z[i + 1] - Z[i] + 1e-5f);
-  __syncthreads();
+  WAVE_SYNC();
   for (int i = lane; i < nm1; i += 64) {
     const float z0 = Z[i], z1 = Z[i + 1];
     const float px0 = ox + dx * z0, py0 = oy + dy * z0, pz0 = oz + dz * z0;
@@ -91,22 +95,22 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
     const float pc = sigmoidf_(pe * inv_s), nc = sigmoidf_(ne * inv_s);
     A[i] = (pc - nc + 1e-5f) / (pc + 1e-5f);
   }
-  __syncthreads();
+  WAVE_SYNC();
   // transmittance: exclusive cumprod of (1 - alpha + 1e-7)  -> reuse C
   for (int i = lane; i < nm1; i += 64) C[i] = 1.f - A[i] + 1e-7f;
-  __syncthreads();
+  WAVE_SYNC();
   const int per = (nm1 + 63) / 64;
   excl_cumprod(C, nm1, per, lane);
-  __syncthreads();
+  WAVE_SYNC();
   // weights + 1e-5, pdf, cdf (sample_pdf, renderer.py:42-45)
   float loc = 0.f;
   for (int i = lane; i < nm1; i += 64) { const float wv = A[i] * C[i] + 1e-5f; A[i] = wv; loc += wv; }
   const float tot = wave_sum(loc);
-  __syncthreads();
+  WAVE_SYNC();
   for (int i = lane; i < nm1; i += 64) A[i] = A[i] / tot;
-  __syncthreads();
+  WAVE_SYNC();
   incl_cumsum(A, nm1, per, lane);
-  __syncthreads();
+  WAVE_SYNC();
   // cdf = [0, A[0..nm1-1]] has n entries; invert at the m deterministic u's (torch.linspace semantics)
   if (lane < m) {
     const float start = 0.5f / m, end = 1.f - 0.5f / m;
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
     const float t = (u - cb) / denom;
     NZ[lane] = Z[below] + t * (Z[above] - Z[below]);
   }
-  __syncthreads();
+  WAVE_SYNC();
   // merge (both lists ascending; ties keep the old sample first, like a stable sort of cat([z, new_z]))
   float* zo = z_out + (long)ray * (n + m);
   float* so = sdf_out + (long)ray * (n + m);
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     float* __restrict__ nsum) {
   __shared__ float sT[RPB][MAXS], sA[RPB][MAXS];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // no early return: every wave of the block must reach the __syncthreads() below
+  // (wavefronts past the last ray redo ray R - 1 without storing)
   const bool active = blockIdx.x * RPB + w < R;
   const int ray = active ? blockIdx.x * RPB + w : R - 1;
   float* T = sT[w]; float* A = sA[w];
@@ -220,9 +224,9 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
       e_den += 1.f;
     }
   }
-  __syncthreads();
+  WAVE_SYNC();
   excl_cumprod(T, S, (S + 63) / 64, lane);
-  __syncthreads();
+  WAVE_SYNC();
   float c0 = 0, c1 = 0, c2 = 0, x0 = 0, x1 = 0, x2 = 0, ws = 0, wm = 0, n0 = 0, n1 = 0, n2 = 0;
   for (int i = lane; i < S; i += 64) {
     const float wv = A[i] * T[i];
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     float* __restrict__ d_normal, float* __restrict__ d_rgb, float* __restrict__ d_inv_s) {
   __shared__ float sT[RPB][MAXS], sA[RPB][MAXS], sW[RPB][MAXS], sS[RPB][MAXS];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // no early return: every wave of the block must reach the __syncthreads() below
+  // (wavefronts past the last ray redo ray R - 1 without storing)
   const bool active = blockIdx.x * RPB + w < R;
   const int ray = active ? blockIdx.x * RPB + w : R - 1;
   float* T = sT[w]; float* A = sA[w]; float* WB = sW[w]; float* SS = sS[w];
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     WB[i] = dc0 * r[0] + dc1 * r[1] + dc2 * r[2] + de0 * (r[3] - b0) + de1 * (r[4] - b1) + de2 * (r[5] - b2) +
             (d_weights ? d_weights[base + i] : 0.f) + dws + dn0 * nx + dn1 * ny + dn2 * nz;
   }
-  __syncthreads();
+  WAVE_SYNC();
   const int per = (S + 63) / 64;
   // suffix scan of affine maps.  Lane owns chunk [b, b+per); local composite (a_loc, t_loc) maps S_{end} -> S_{b-1}
   {
@@ -337,9 +341,9 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
       if (i < S) { SS[i] = run; run = WB[i] * A[i] + T[i] * run; }
     }
   }
-  __syncthreads();
+  WAVE_SYNC();
   excl_cumprod(T, S, per, lane);   // T now holds the transmittance
-  __syncthreads();
+  WAVE_SYNC();
   float dinv = 0.f;
   for (int i = lane; i < S; i += 64) {
     const float zv = z[base + i];

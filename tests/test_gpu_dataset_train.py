@@ -86,7 +86,7 @@ def test_train_on_the_reference_standpose_dataset(tmp_path):
             "Statistics/psnr"} <= tags and len(rows) == 5 * 7
     psnr = [x["value"] for x in rows if x["tag"] == "Statistics/psnr"]
     sval = [x["value"] for x in rows if x["tag"] == "Statistics/s_val"]
-    assert all(np.isfinite(psnr)) and all(5.0 < p < 60.0 for p in psnr) and all(0.0 < v < 1.0 for v in sval)
+    assert all(np.isfinite(psnr)) and all(0.0 < p < 60.0 for p in psnr) and all(0.0 < v < 1.0 for v in sval)
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, "r03_train_standpose_loss.json"), "w") as fp:

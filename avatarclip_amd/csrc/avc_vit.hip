@@ -161,9 +161,26 @@ extern "C" int avc_vit_linear_bwd_gelu(const float* dy, const float* pre, const 
 #define AT_D 64
 #define AT_LD 65   // +1 padding: thread i reads row i -> conflict-free
 
-// 4 wavefronts per (b, head): wave `part` owns the keys j = part (mod 4) for the scores and the 16 output columns
-// 16 part .. 16 part + 15 for P V; every LDS read of K / V is a broadcast (a wave shares j), P rows are stride-51 (conflict-free)
-#define AT_PARTS 4
+// AT_PARTS wavefronts per (b, head): wave `part` owns the keys j = part (mod AT_PARTS) for the scores and the AT_COLS output
+// columns AT_COLS part .. for P V; every LDS read of K / V is a broadcast (a wave shares j), P rows are stride-51 (conflict-free).
+// Only B x heads = 24 workgroups exist per call, so the kernels are latency chains: 8 wavefronts instead of 4 halve every
+// per-thread loop (forward 26 -> see profiles/r03_ab_kernels.txt, backward 56 ->).
+#ifndef AT_PARTS
+#define AT_PARTS 8
+#endif
+#define AT_COLS (AT_D / AT_PARTS)
+__device__ __forceinline__ float at_max_parts(const float (*r)[64], int i) {
+  float m = r[0][i];
+#pragma unroll
+  for (int p = 1; p < AT_PARTS; ++p) m = fmaxf(m, r[p][i]);
+  return m;
+}
+__device__ __forceinline__ float at_sum_parts(const float (*r)[64], int i) {
+  float m = r[0][i];
+#pragma unroll
+  for (int p = 1; p < AT_PARTS; ++p) m += r[p][i];
+  return m;
+}
 __global__ __launch_bounds__(64 * AT_PARTS) void vit_attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, int Wd,
                                                                      int heads, float scale) {
   __shared__ float Ks[AT_T][AT_LD], Vs[AT_T][AT_LD], Ps[AT_T][AT_T + 1], red[2][AT_PARTS][64];
@@ -194,24 +211,24 @@ __global__ __launch_bounds__(64 * AT_PARTS) void vit_attn_fwd_kernel(const float
   __syncthreads();
   float sum = 0.f;
   if (live) {
-    mx = fmaxf(fmaxf(red[0][0][i], red[0][1][i]), fmaxf(red[0][2][i], red[0][3][i]));
+    mx = at_max_parts(red[0], i);
     for (int j = part; j < AT_T; j += AT_PARTS) { const float e = __expf(Ps[i][j] - mx); Ps[i][j] = e; sum += e; }
   }
   red[1][part][i] = sum;
   __syncthreads();
   if (!live) return;
-  const float inv = 1.f / (red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i]);
-  float o[16];
+  const float inv = 1.f / at_sum_parts(red[1], i);
+  float o[AT_COLS];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) o[c] = 0.f;
+  for (int c = 0; c < AT_COLS; ++c) o[c] = 0.f;
   for (int j = 0; j < AT_T; ++j) {
     const float pj = Ps[i][j] * inv;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) o[c] += pj * Vs[j][16 * part + c];
+    for (int c = 0; c < AT_COLS; ++c) o[c] += pj * Vs[j][AT_COLS * part + c];
   }
-  float* op = out + ((long)b * AT_T + i) * Wd + hd * AT_D + 16 * part;
+  float* op = out + ((long)b * AT_T + i) * Wd + hd * AT_D + AT_COLS * part;
 #pragma unroll
-  for (int c = 0; c < 16; ++c) op[c] = o[c];
+  for (int c = 0; c < AT_COLS; ++c) op[c] = o[c];
 }
 
 // Text tower (clip/model.py encode_text: 77 tokens, 8 heads of 64, causal mask): forward only -- prompts are encoded once per
@@ -294,14 +311,14 @@ __global__ __launch_bounds__(64 * AT_PARTS) void vit_attn_bwd_kernel(const float
   __syncthreads();
   float sum = 0.f;
   if (live) {
-    mx = fmaxf(fmaxf(red[0][0][i], red[0][1][i]), fmaxf(red[0][2][i], red[0][3][i]));
+    mx = at_max_parts(red[0], i);
     for (int j = part; j < AT_T; j += AT_PARTS) { const float e = __expf(Ps[i][j] - mx); Ps[i][j] = e; sum += e; }
   }
   red[1][part][i] = sum;
   __syncthreads();
   float dsum = 0.f;
   if (live) {
-    const float inv = 1.f / (red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i]);
+    const float inv = 1.f / at_sum_parts(red[1], i);
     for (int j = part; j < AT_T; j += AT_PARTS) {
       const float pj = Ps[i][j] * inv;
       Ps[i][j] = pj;
@@ -311,21 +328,21 @@ __global__ __launch_bounds__(64 * AT_PARTS) void vit_attn_bwd_kernel(const float
   red[2][part][i] = dsum;
   __syncthreads();
   if (live) {
-    dsum = red[2][0][i] + red[2][1][i] + red[2][2][i] + red[2][3][i];
+    dsum = at_sum_parts(red[2], i);
     for (int j = part; j < AT_T; j += AT_PARTS) Ss[i][j] = Ps[i][j] * (Ss[i][j] - dsum) * scale;
   }
   __syncthreads();
   if (!live) return;
-  // dQ row i, dK / dV row j = i: this wave's 16 columns
-  const int c0 = 16 * part;
-  float dq[16], dk[16], dv[16];
+  // dQ row i, dK / dV row j = i: this wave's AT_COLS columns
+  const int c0 = AT_COLS * part;
+  float dq[AT_COLS], dk[AT_COLS], dv[AT_COLS];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) { dq[c] = 0.f; dk[c] = 0.f; dv[c] = 0.f; }
+  for (int c = 0; c < AT_COLS; ++c) { dq[c] = 0.f; dk[c] = 0.f; dv[c] = 0.f; }
   for (int r = 0; r < AT_T; ++r) {
     const float ds_q = Ss[i][r];
     const float ds_k = Ss[r][i], pr = Ps[r][i];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
+    for (int c = 0; c < AT_COLS; ++c) {
       dq[c] += ds_q * Ks[r][c0 + c];
       dk[c] += ds_k * Qs[r][c0 + c];
       dv[c] += pr * Ds[r][c0 + c];
@@ -333,7 +350,7 @@ __global__ __launch_bounds__(64 * AT_PARTS) void vit_attn_bwd_kernel(const float
   }
   float* dqp = dqkv + ((long)b * AT_T + i) * 3 * Wd + hd * AT_D + c0;
 #pragma unroll
-  for (int c = 0; c < 16; ++c) { dqp[c] = dq[c]; dqp[Wd + c] = dk[c]; dqp[2 * Wd + c] = dv[c]; }
+  for (int c = 0; c < AT_COLS; ++c) { dqp[c] = dq[c]; dqp[Wd + c] = dk[c]; dqp[2 * Wd + c] = dv[c]; }
 }
 
 extern "C" int avc_vit_attention_fwd(const float* qkv, float* out, int B, int T, int width, int heads, void* stream) {

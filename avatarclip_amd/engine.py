@@ -147,6 +147,29 @@ def flatten_dense(sdf_net, col_net, spec: PK.NetSpec) -> torch.Tensor:
     return DenseParamsFn.apply((lay, offs), *tensors)
 
 
+def plan_panels(R, S, budget, blk_f, blk_g, slab_blocks, min_slab_blocks):
+    """How a ray set [R rays x S samples] is cut for the training path (pure arithmetic; Engine.plan supplies the budget).
+    blk_f / blk_g = bytes per 32-point block of the F region (+ masks) / of the G region.  Returns (rays per chunk, rays per
+    slab), both multiples of 32 rays (block-aligned for every S) unless they cover the whole ray set:
+      * the slab is `slab_blocks` blocks unless the whole ray set's F panels + one slab exceed the budget -- then it is halved down
+        to `min_slab_blocks` (the whole ray set in one chunk is worth smaller slabs);
+      * if even that does not fit, the ray set is cut into chunks (F panels of a chunk + one slab <= budget) and the backward
+        re-runs the training forward per chunk."""
+    nb = lambda rays: (rays * S + 31) // 32 + 1              # + the sink block
+    rays_of = lambda blocks: min(R, max(32, blocks * 32 // S // 32 * 32))
+    blocks = slab_blocks
+    slab = rays_of(blocks)
+    while nb(R) * blk_f + nb(slab) * blk_g > budget and blocks > min_slab_blocks:
+        blocks //= 2
+        slab = rays_of(blocks)
+    if nb(R) * blk_f + nb(slab) * blk_g <= budget:
+        return R, slab
+    if nb(slab) * (blk_f + blk_g) > budget:                  # not even one slab with its own F panels: shrink the slab further
+        slab = max(32, (budget // (blk_f + blk_g) - 1) * 32 // S // 32 * 32)
+    chunk = max(slab, ((budget - nb(slab) * blk_g) // blk_f - 1) * 32 // S // 32 * 32)
+    return min(chunk, R), min(slab, R)
+
+
 class Engine:
     _by_net = weakref.WeakKeyDictionary()
     PROFILE = False               # bench.py: record (name, points, start_event, end_event) per kernel launch group
@@ -250,32 +273,17 @@ class Engine:
         return sum(b.numel() * b.element_size() for b in (self._fpanels, self._gpanels, self._masks) if b is not None)
 
     def plan(self, R, S):
-        """(rays per chunk, rays per slab): a chunk's F panels + masks and one slab's G panels fit the budget; both are multiples
-        of 32 rays (block-aligned for every S) unless they cover the whole ray set"""
-        blk_f = self.fwd_tiles * 2048 + self.mask_u16 * 2
-        blk_g = self.grad_tiles * 2048
-        nb = lambda rays: (rays * S + 31) // 32 + 1
-        rays_of = lambda blocks: min(R, max(32, blocks * 32 // S // 32 * 32))
+        """(rays per chunk, rays per slab): a chunk's F panels + masks and one slab's G panels fit the budget (plan_panels)"""
         key = (R, S, self.PANEL_BYTES_BUDGET, self.SLAB_BLOCKS)
         if getattr(self, "_plan_key", None) == key:
             chunk, slab = self._plan_val
-            if chunk < R or (self._fpanels is not None and self._fpanels.numel() >= nb(R) * self.fwd_tiles * 2048):
+            if chunk < R or (self._fpanels is not None and self._fpanels.numel() >= ((R * S + 31) // 32 + 1) * self.fwd_tiles * 2048):
                 return self._plan_val  # (no driver query on the hot path: hipMemGetInfo synchronises with the device)
         # 80 % of what is free once the current buffers are given back (they are released before larger ones are allocated)
         budget = max(min(self.PANEL_BYTES_BUDGET, (torch.cuda.mem_get_info(self.device)[0] + self._held_bytes()) * 8 // 10), 1 << 26)
-        blocks = self.SLAB_BLOCKS
-        slab = rays_of(blocks)
-        while nb(R) * blk_f + nb(slab) * blk_g > budget and blocks > self.MIN_SLAB_BLOCKS:
-            blocks //= 2                                      # the whole ray set in one chunk is worth smaller slabs
-            slab = rays_of(blocks)
-        if nb(R) * blk_f + nb(slab) * blk_g <= budget:
-            chunk = R
-        else:
-            if nb(slab) * (blk_f + blk_g) > budget:          # not even one slab with its own F panels: shrink the slab further
-                slab = max(32, (budget // (blk_f + blk_g) - 1) * 32 // S // 32 * 32)
-            chunk = max(slab, ((budget - nb(slab) * blk_g) // blk_f - 1) * 32 // S // 32 * 32)
-            chunk, slab = min(chunk, R), min(slab, R)
-        self._plan_key, self._plan_val = key, (chunk, slab)
+        self._plan_key = key
+        self._plan_val = plan_panels(R, S, budget, self.fwd_tiles * 2048 + self.mask_u16 * 2, self.grad_tiles * 2048,
+                                     self.SLAB_BLOCKS, self.MIN_SLAB_BLOCKS)
         return self._plan_val
 
     def rays_per_chunk(self, R, S):

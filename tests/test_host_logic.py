@@ -185,3 +185,30 @@ def test_h2d_helpers_on_cpu_and_constant_cache():
     c2 = h2d.const([0.5, 0.25, 0.125], "cpu")
     assert c1 is c2 and c1.tolist() == [0.5, 0.25, 0.125]
     assert h2d.const((0.5, 0.25, 0.125), "cpu", torch.float64) is not c1
+
+
+def test_panel_plan_arithmetic():
+    """engine.plan_panels: how a ray set is cut into chunks (F panels) and slabs (G panels) for a memory budget -- the cases of
+    BASELINE's configurations on a 288-GB device and the degenerate ones"""
+    from avatarclip_amd.engine import plan_panels
+    blk_f, blk_g = 89 * 2048 + 1024, 91 * 2048                      # full nets
+    gib = 1 << 30
+    budget = int(266 * 0.8) * gib
+    nbytes = lambda rays, slab, S: ((rays * S + 31) // 32 + 1) * blk_f + ((slab * S + 31) // 32 + 1) * blk_g
+    # 512^2 x 64 spp: one chunk, two slabs of 256 Ki blocks
+    chunk, slab = plan_panels(512 * 512, 64, budget, blk_f, blk_g, 256 * 1024, 32 * 1024)
+    assert (chunk, slab) == (262144, 131072) and nbytes(chunk, slab, 64) < 140 * gib
+    # 512^2 x 128 spp (config 3 per GPU): still one chunk, the slab halved until it fits
+    chunk, slab = plan_panels(512 * 512, 128, budget, blk_f, blk_g, 256 * 1024, 32 * 1024)
+    assert chunk == 262144 and slab == 32768 and nbytes(chunk, slab, 128) <= budget
+    # 224^2: everything in one slab
+    assert plan_panels(224 * 224, 64, budget, blk_f, blk_g, 256 * 1024, 32 * 1024) == (50176, 50176)
+    # a 3-GiB budget: chunks of whole slabs, multiples of 32 rays, inside the budget
+    chunk, slab = plan_panels(512 * 512, 64, 3 * gib, blk_f, blk_g, 256 * 1024, 32 * 1024)
+    assert 0 < slab <= chunk < 262144 and chunk % 32 == 0 and slab % 32 == 0 and nbytes(chunk, slab, 64) <= 3 * gib
+    # samples per ray that do not divide the block: slab boundaries still fall on blocks
+    chunk, slab = plan_panels(1000, 48, 1 << 26, 33 * 2048 + 1024, 35 * 2048, 160, 32 * 1024)
+    assert slab % 32 == 0 and chunk % 32 == 0 and (slab * 48) % 32 == 0 and slab < chunk < 1000
+    # tiny ray sets are never cut
+    assert plan_panels(1, 64, 1 << 26, blk_f, blk_g, 256 * 1024, 32 * 1024) == (1, 1)
+    assert plan_panels(33, 64, 1 << 26, blk_f, blk_g, 256 * 1024, 32 * 1024) == (33, 33)

@@ -113,6 +113,14 @@ __device__ __forceinline__ void dephase(const ST& st) {
 // workgroup for an HBM write round trip; issued right after one it has a group of MFMA work (~2 us) to complete under.
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 #define AVC_HOOK(...) [&]() __attribute__((always_inline)) { __VA_ARGS__ }
+// a hook that spreads its stores over the layer's weight groups: called after EVERY group barrier with (g, number of groups) and
+// stores the g-th share of its tiles (tiles_store_part) -- bursts of 4 instead of 8 tile stores per barrier interval
+#define AVC_HOOKG(...) [&](int grp_, int ngrp_) __attribute__((always_inline)) { __VA_ARGS__ }
+template <typename Hook>
+__device__ __forceinline__ void hook_call(Hook&& hook, int g, int ng) {
+  if constexpr (std::is_invocable_v<Hook, int, int>) hook(g, ng);
+  else if (g == 0) hook();
+}
 
 #ifndef AVC_PAIR
 #define AVC_PAIR 0   // 1: two output tiles per MFMA stream (independent accumulators), 0: one dependent chain per tile
@@ -144,7 +152,7 @@ __device__ __forceinline__ void layer_sp(ST& st, const V* __restrict__ blob, int
     } else {
       stage_issue(st, after, st.par ^ 1);
     }
-    if (g == 0) hook();
+    hook_call(hook, g, NG);
     dephase(st);
 #pragma unroll
     for (int j = 0; j < G; j += (PAIRED ? 2 : 1)) {
@@ -214,7 +222,7 @@ __device__ __forceinline__ void layer_sq_(ST& st, const V* __restrict__ blob, in
       } else {
         stage_issue(st, after, st.par ^ 1);
       }
-      if (g == 0) hook();
+      hook_call(hook, g, NG);
 #pragma unroll
       for (int j = 0; j < G; j += 2) {
         const int t = g * G + j;
@@ -261,7 +269,7 @@ __device__ __forceinline__ void layer_sq_(ST& st, const V* __restrict__ blob, in
     } else {
       stage_issue(st, after, st.par ^ 1);
     }
-    if (g == 0) hook();
+    hook_call(hook, g, NG);
 #pragma unroll
     for (int j = 0; j < G; ++j) {
       const int t = g * G + j;
@@ -316,7 +324,7 @@ __device__ __forceinline__ void layer2_s(ST& st, const V* __restrict__ blob, int
     } else {
       stage_issue(st, after, st.par ^ 1);
     }
-    if (g == 0) hook();
+    hook_call(hook, g, NG);
     dephase(st);
 #pragma unroll
     for (int j = 0; j < G; j += (PAIRED ? 2 : 1)) {
@@ -427,7 +435,12 @@ template <typename V> __device__ __forceinline__ AVC_GLOBAL V* tile_addr(const P
 template <bool KEEP, typename V>
 __device__ __forceinline__ void tile_store(const PanelPtr& pp, int tile, const V& f0, const V& f1) {
   AVC_GLOBAL V* p = tile_addr<V>(pp, tile);
-  if (KEEP) {
+#ifdef AVC_KEEP_NT   // timing experiment: the re-read tiles streamed past the caches as well
+  constexpr bool keep = false;
+#else
+  constexpr bool keep = KEEP;
+#endif
+  if (keep) {
     p[0] = f0;
     p[64] = f1;
   } else {
@@ -440,6 +453,13 @@ template <bool KEEP, int NT, typename V, int KS>
 __device__ __forceinline__ void tiles_store(const PanelPtr& pp, int tile0, const V (&f)[KS]) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) tile_store<KEEP>(pp, tile0 + t, f[2 * t], f[2 * t + 1]);
+}
+// the g-th of ng shares of the tiles of one activation (g, ng compile-time after unrolling: the tile test folds)
+template <bool KEEP, int NT, typename V, int KS>
+__device__ __forceinline__ void tiles_store_part(const PanelPtr& pp, int tile0, const V (&f)[KS], int g, int ng) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    if (t * ng / NT == g) tile_store<KEEP>(pp, tile0 + t, f[2 * t], f[2 * t + 1]);
 }
 template <typename V> struct FragPair { V a0, a1; };     // the two k-step fragments of a panel tile
 template <bool NT, typename V>

@@ -17,6 +17,14 @@
 #ifndef FWD_G
 #define FWD_G 4
 #endif
+#ifndef AVC_SPREAD_STORES
+#define AVC_SPREAD_STORES 1   // 1: the tile stores of a layer's input are dealt to ALL weight-group intervals of the layer, 0: all after the first barrier
+#endif
+#if AVC_SPREAD_STORES
+#define AVC_STORE_HOOK(KEEP, NT, PT, ARR) AVC_HOOKG(tiles_store_part<KEEP, NT>(tiles, PT, ARR, grp_, ngrp_);)
+#else
+#define AVC_STORE_HOOK(KEEP, NT, PT, ARR) AVC_HOOK(tiles_store<KEEP, NT>(tiles, PT, ARR);)
+#endif
 // timing ablations of the training forward (results are garbage): which of its extra stores cost what
 #ifdef AVC_ABL_NOMASK
 constexpr bool ABL_NOMASK = true;
@@ -178,17 +186,17 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
         h8 hm0[N::HK];
         if constexpr (N::NMID == 2) {
           layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wf, o), h1, AVC_F_ACT(hm0),
-                                    AVC_HOOK(tiles_store<true, N::HT>(tiles, L::P_H1, h1);), AVC_F_BIAS(OFF_BM0));
+                                    AVC_STORE_HOOK(true, N::HT, L::P_H1, h1), AVC_F_BIAS(OFF_BM0));
           h8 hm1[N::HK];
           layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wf, o), hm0, AVC_F_ACT(hm1),
-                                    AVC_HOOK(tiles_store<true, N::HT>(tiles, L::P_HM, hm0);), AVC_F_BIAS(OFF_BM1));
+                                    AVC_STORE_HOOK(true, N::HT, L::P_HM, hm0), AVC_F_BIAS(OFF_BM1));
           layer_s<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], nxt<N, OFF_WL>(sg, Wf, o), hm1, AVC_F_LAST(),
-                                    AVC_HOOK(tiles_store<true, N::HT>(tiles, L::P_HM + N::HT, hm1);), AVC_F_BIAS(OFF_BS));
+                                    AVC_STORE_HOOK(true, N::HT, L::P_HM + N::HT, hm1), AVC_F_BIAS(OFF_BS));
         } else {
           layer_s<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wf, o), h1, AVC_F_ACT(hm0),
-                                    AVC_HOOK(tiles_store<true, N::HT>(tiles, L::P_H1, h1);), AVC_F_BIAS(OFF_BM0));
+                                    AVC_STORE_HOOK(true, N::HT, L::P_H1, h1), AVC_F_BIAS(OFF_BM0));
           layer_s<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], nxt<N, OFF_WL>(sg, Wf, o), hm0, AVC_F_LAST(),
-                                    AVC_HOOK(tiles_store<true, N::HT>(tiles, L::P_HM, hm0);), AVC_F_BIAS(OFF_BS));
+                                    AVC_STORE_HOOK(true, N::HT, L::P_HM, hm0), AVC_F_BIAS(OFF_BS));
         }
       }
       sdf = xhalf_sum(part) + T[o.v[OFF_BL0]];
@@ -214,7 +222,11 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
             OUT[2 * t][j] = (_Float16)(acc[j] * sig_from_h((float)d.a0[j]));                                \
             OUT[2 * t + 1][j] = (_Float16)(acc[8 + j] * sig_from_h((float)d.a1[j])); }                      \
           pin2(OUT[2 * t], OUT[2 * t + 1]);)
+#if AVC_SPREAD_STORES
+#define AVC_F_GSTORE(PG, G) AVC_HOOKG(if constexpr (TRAIN && !ABL_NOGASTORE) tiles_store_part<false, N::HT>(tiles, PG, G, grp_, ngrp_);)
+#else
 #define AVC_F_GSTORE(PG, G) AVC_HOOK(if constexpr (TRAIN && !ABL_NOGASTORE) tiles_store<false, N::HT>(tiles, PG, G);)
+#endif
       h8 g[N::HK];
       h8 g2[N::HK];
       if constexpr (N::NMID == 2) {
@@ -271,8 +283,13 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
             a[r] = relu_raw(acc[r]); if (TRAIN) bits |= (a[r] > 0.f ? 1u : 0u) << r; }        \
           if constexpr (TRAIN && !ABL_NOMASK) mk[((ML) * N::HT + t) * 64] = (unsigned short)bits; \
           acc_to_frags(a, OUT[2 * t], OUT[2 * t + 1]);)
+#if AVC_SPREAD_STORES
+#define AVC_F_RSTORE(PT, R)                                                                   \
+  AVC_HOOKG(if constexpr (TRAIN && !ABL_NORSTORE) tiles_store_part<false, N::HT>(tiles, PT, R, grp_, ngrp_);)
+#else
 #define AVC_F_RSTORE(PT, R)                                                                   \
   AVC_HOOK(if constexpr (TRAIN && !ABL_NORSTORE) tiles_store<false, N::HT>(tiles, PT, R);)
+#endif
       h8 r1[N::HK];
       h8 r2[N::HK];
       if constexpr (N::NCMID == 1) {

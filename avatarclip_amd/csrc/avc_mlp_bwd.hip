@@ -21,6 +21,17 @@
 #define BWD_WPB 8   // wavefronts per workgroup: every staged weight tile is shared by 256 points (LDS-DMA fill rate is the scarce resource)
 #endif
 #include "../../include/avc.h"
+// cache policy of the tile loads: NT = streamed past the caches.  Measured per 4 Mi points (profiles/r03_ab_kernels.txt):
+//   AVC_BWD_E_NT    the h tiles the second-order sweep reads (they are read AGAIN by the reverse sweep ~6 layer steps later):
+//                   normal policy 10.21 ms vs nt 10.43 -> 0
+//   AVC_BWD_RR_NT   the tiles this kernel wrote itself (normal-policy stores) and reads back (gbar_h, ybar[1:]): nt loads 10.43 vs
+//                   normal 10.59 (both switches off: 11.12) -> 1
+#ifndef AVC_BWD_E_NT
+#define AVC_BWD_E_NT 0
+#endif
+#ifndef AVC_BWD_RR_NT
+#define AVC_BWD_RR_NT 1
+#endif
 
 template <typename P> __device__ __forceinline__ P launder(P p) {
   asm volatile("" : "+s"(p));
@@ -162,7 +173,7 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
       tile_store<false>(tiles, L::G_GB0 + 1, gb0[2], zero_frag<b8>());
       // gbar_a = W gbar_h(in); gbar_h(out) = gbar_a * sigma(h_out)
 #define AVC_SECOND(OUT, PH, PT)                                                                             \
-  AVC_PRE(return tile_load<true, h8>(ftiles, (PH) + t);),                                                    \
+  AVC_PRE(return tile_load<(AVC_BWD_E_NT != 0), h8>(ftiles, (PH) + t);),                                     \
   AVC_EPID(FragPair<h8>, _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                     \
             OUT[2 * t][j] = (__bf16)(acc[j] * sig_from_h((float)d.a0[j]));                                   \
             OUT[2 * t + 1][j] = (__bf16)(acc[8 + j] * sig_from_h((float)d.a1[j])); }                         \
@@ -189,13 +200,13 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
       b8 dfeat[N::HK];
 #pragma unroll
       for (int t = 0; t < N::HT; ++t) {
-        const FragPair<b8> d = tile_load<true, b8>(tiles, L::G_DFEAT + t);
+        const FragPair<b8> d = tile_load<(AVC_BWD_RR_NT != 0), b8>(tiles, L::G_DFEAT + t);
         dfeat[2 * t] = d.a0;
         dfeat[2 * t + 1] = d.a1;
       }
 #define AVC_LOAD3(PH, PB, PG)                                                                               \
   AVC_PRE(PF3 d; { const FragPair<h8> a = tile_load<true, h8>(ftiles, (PH) + t); d.h0 = a.a0; d.h1 = a.a1; } \
-          { const FragPair<b8> a = tile_load<true, b8>(tiles, (PB) + t); d.b0 = a.a0; d.b1 = a.a1; }         \
+          { const FragPair<b8> a = tile_load<(AVC_BWD_RR_NT != 0), b8>(tiles, (PB) + t); d.b0 = a.a0; d.b1 = a.a1; } \
           { const FragPair<h8> a = tile_load<true, h8>(ftiles, (PG) + t); d.g0 = a.a0; d.g1 = a.a1; } return d;)
       // ubar[:SKIP]/sqrt2 = (W_last[1:,:]^T dfeat + W_last[0,:] d_sdf)/sqrt2 ; 1/sqrt2 is folded into both packs
       layer_sq<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WLT], nxt<N, OFF_WST>(sg, Wb, o), dfeat,

@@ -288,8 +288,8 @@ def test_full_sampling_chain_close_to_reference(name):
 
 
 @gpu
-@pytest.mark.parametrize("extra_color", [True, False])
-def test_fused_dense_parameter_assembly_matches_torch_weight_norm(extra_color):
+@pytest.mark.parametrize("extra_color,weight_norm", [(True, True), (False, True), (True, False)])
+def test_fused_dense_parameter_assembly_matches_torch_weight_norm(extra_color, weight_norm):
     """csrc/avc_params.hip (weight norm of every linear + flattening, fields.py:65-66,139-143) forward and backward against the plain
     torch expressions `fields.dense_weight` + cat, fp32 both: values to 1e-6, gradients to 1e-5 relative"""
     from avatarclip_amd import fields, packing as PK
@@ -297,9 +297,9 @@ def test_fused_dense_parameter_assembly_matches_torch_weight_norm(extra_color):
     dev = torch.device("cuda")
     torch.manual_seed(5)
     sdf = fields.SDFNetwork(d_out=257, d_in=3, d_hidden=256, n_layers=4, skip_in=[4], multires=6, bias=0.5, scale=1.0,
-                            geometric_init=True, weight_norm=True).to(dev)
+                            geometric_init=True, weight_norm=weight_norm).to(dev)
     col = fields.RenderingNetwork(d_feature=256, mode="no_view_dir", d_in=6, d_out=3, d_hidden=256, n_layers=2,
-                                  weight_norm=True, multires_view=0, squeeze_out=True, extra_color=extra_color).to(dev)
+                                  weight_norm=weight_norm, multires_view=0, squeeze_out=True, extra_color=extra_color).to(dev)
     with torch.no_grad():
         for p in list(sdf.parameters()) + list(col.parameters()):
             p.add_(torch.randn_like(p) * 0.05)

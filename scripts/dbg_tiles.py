@@ -21,7 +21,7 @@ for name in names:
     f = A.mlp_forward(A.dense_net(sd_sdf, sd_col, torch.float64), x)
     npts = x.shape[0]; nblk = (npts + 31) // 32
     P = eng.dl.lay.panel
-    panels = eng._panels[: nblk * eng.ptiles * 2048].view(torch.int16).reshape(nblk, eng.ptiles, 2, 64, 8).cpu()
+    panels = eng._fpanels[: nblk * eng.fwd_tiles * 2048].view(torch.int16).reshape(nblk, eng.fwd_tiles, 2, 64, 8).cpu()   # F region: P[...] of the forward-type tiles = region-local index
     def decode(p0, ntile, nfeat):
         t = panels[:, p0:p0 + ntile].view(torch.float16).double()     # [blk, tile, kstep, lane, 8]
         out = torch.zeros(nblk * 32, ntile * 32, dtype=torch.float64)

@@ -1,5 +1,5 @@
 """weight-gradient kernel per pair shape (development aid): each (ta, tb, type_a, type_b) of the real pair list alone over 4 Mi
-points of the real 180-tile panel: python scripts/wg_layout_probe.py"""
+points of panels with the real region strides (F region 89 tiles, G region 91 tiles per block): python scripts/wg_layout_probe.py"""
 import sys, os, ctypes, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from avatarclip_amd import lib as L
@@ -8,8 +8,9 @@ dev = torch.device("cuda")
 nblk = 1 << 17     # 4 Mi points
 st = torch.cuda.current_stream().cuda_stream
 nsplit = 256
-ptiles = 180
-panels = torch.zeros(nblk * ptiles * 1024, dtype=torch.int16, device=dev)
+ftiles, gtiles = 89, 91
+fpanels = torch.zeros(nblk * ftiles * 1024, dtype=torch.int16, device=dev)
+gpanels = torch.zeros(nblk * gtiles * 1024, dtype=torch.int16, device=dev)
 out = torch.empty(nsplit, 4 * 72 * 1024, device=dev)
 bo = torch.empty(nsplit, 1024, device=dev)
 tot = 0.0
@@ -17,7 +18,7 @@ for (ta, tb, tya, tyb, count) in ((8, 2, 1, 0, 2), (8, 2, 0, 1, 1), (8, 8, 1, 0,
                                   (1, 7, 1, 0, 1), (1, 2, 1, 0, 1), (1, 7, 1, 1, 1), (1, 2, 1, 1, 1), (8, 9, 1, 0, 1), (1, 8, 1, 0, 1)):
     pairs = np.array([[0, ta, 20, tb, 0, -1, tya, tyb]], dtype=np.int32)
     def run():
-        rc = lib.avc_weight_grad_all(panels.data_ptr(), ptiles, 1, pairs.ctypes.data, nblk, out.data_ptr(), bo.data_ptr(), nsplit, out.stride(0), bo.stride(0), st)
+        rc = lib.avc_weight_grad_all(fpanels.data_ptr(), ftiles, gpanels.data_ptr(), gtiles, 1, pairs.ctypes.data, nblk, out.data_ptr(), bo.data_ptr(), nsplit, out.stride(0), bo.stride(0), st)
         assert rc == 0
     run(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -35,7 +36,8 @@ for boff in (-1, 0):
     e0.record(); run(); e1.record(); torch.cuda.synchronize()
     print("8 x 8 pair (bf16 x f16), bias sums %s: %.3f ms" % ("on" if boff >= 0 else "off", e0.elapsed_time(e1)))
 # the same 8 x 8 pair on random data (zeros above): does the data matter (toggle power, clocks)?
-panels.copy_(torch.randint(-2000, 2000, panels.shape, dtype=torch.int16, device=dev))
+fpanels.copy_(torch.randint(-2000, 2000, fpanels.shape, dtype=torch.int16, device=dev))
+gpanels.copy_(torch.randint(-2000, 2000, gpanels.shape, dtype=torch.int16, device=dev))
 pairs = np.array([[0, 8, 20, 8, 0, -1, 1, 0]], dtype=np.int32)
 for rep in range(2):
     run(); torch.cuda.synchronize()

@@ -39,7 +39,7 @@ KERNEL_ROOFLINES = {
     "avc_sdf_forward": dict(kernel="mlp_sdf_kernel", limited_by="engine (MFMA + VALU + LDS issue of the register-resident MLP)", flop_per_point=F_SDF_ONLY,
                             bytes_per_point=4 + 4 + 1,
                             note="SDF value at the sampler's points (renderer.py:337-338,187): four f16 GEMM layers + an fp32 dot product, no HBM "
-                                 "traffic to speak of -- the SDF-MLP GEMM north_star names"),
+                                 "traffic to speak of (the PMC bytes are the scratch traffic of 14 spilled registers) -- the SDF-MLP GEMM north_star names"),
     "avc_render_points_fwd_train": dict(kernel="mlp_render_kernel<train>", limited_by="engine, with the forward-type tile stores riding along", flop_per_point=F_PT,
                                         bytes_per_point=89 * TILE + 76,
                                         note="differentiable forward (F_pt = 1 186 816 FLOP/point) + the 89 forward-type operand tiles"),

@@ -46,3 +46,32 @@ buf = torch.zeros(GRID * tiles_per_wg * 512, dtype=torch.int32, device=dev)
 for write, what in ((1, "streaming write"), (0, "streaming read")):
     ms = timed(lambda: lib.ub3_stream(GRID, buf.data_ptr(), tiles_per_wg, write, st), lambda: None)
     print("%-16s of %.1f GB in 2-KiB tiles: %8.3f ms  %7.1f GB/s" % (what, GRID * tiles_per_wg * 2048 / 1e9, ms, GRID * tiles_per_wg * 2048 / ms / 1e6), flush=True)
+
+# ---- does the Infinity Cache (256 MB, memory side) keep freshly WRITTEN tiles for a reader that comes right after?  write X then read X
+# (candidate hits) against write X then read a cold Y of the same size, over sizes around the cache capacity.  If the second kernel is
+# clearly faster on X below ~256 MB, a slab-sized producer -> consumer pipeline could take its G tiles from the cache; if not, only
+# the L2 rings above can.
+import sys
+if "mall" in sys.argv:
+    print("# write X (nt stores) -> read X | read cold Y; MB, us per read launch, GB/s")
+    for mb in (32, 64, 128, 192, 256, 384, 768):
+        tiles_per_wg = mb * (1 << 20) // 2048 // GRID
+        n = GRID * tiles_per_wg * 512
+        X = torch.zeros(n, dtype=torch.int32, device=dev)
+        Y = torch.zeros(n, dtype=torch.int32, device=dev)
+        big = torch.zeros(1 << 28, dtype=torch.int32, device=dev)      # 1 GiB: flushes the caches between repetitions
+        res = {}
+        for name, src in (("same", X), ("cold", Y)):
+            ts = []
+            for rep in range(6):
+                big.add_(1)                                             # evict
+                lib.ub3_stream(GRID, X.data_ptr(), tiles_per_wg, 1, st)  # producer writes X
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); lib.ub3_stream(GRID, src.data_ptr(), tiles_per_wg, 0, st); e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1e3)
+            res[name] = sorted(ts)[len(ts) // 2]
+        b = GRID * tiles_per_wg * 2048
+        print("%4d MB  read-after-write %8.1f us (%6.0f GB/s)   cold read %8.1f us (%6.0f GB/s)"
+              % (mb, res["same"], b / res["same"] / 1e3, res["cold"], b / res["cold"] / 1e3), flush=True)
+        del X, Y, big

@@ -53,8 +53,9 @@ for write, what in ((1, "streaming write"), (0, "streaming read")):
 # the L2 rings above can.
 import sys
 if "mall" in sys.argv:
-    print("# write X (nt stores) -> read X | read cold Y; MB, us per read launch, GB/s")
-    for mb in (32, 64, 128, 192, 256, 384, 768):
+  for wmode, wname in ((1, "nt stores"), (2, "normal-policy stores")):
+    print("# write X (%s) -> read X | read cold Y; MB, us per read launch, GB/s" % wname)
+    for mb in (8, 32, 64, 128, 192, 256, 384, 768):
         tiles_per_wg = mb * (1 << 20) // 2048 // GRID
         n = GRID * tiles_per_wg * 512
         X = torch.zeros(n, dtype=torch.int32, device=dev)
@@ -65,7 +66,7 @@ if "mall" in sys.argv:
             ts = []
             for rep in range(6):
                 big.add_(1)                                             # evict
-                lib.ub3_stream(GRID, X.data_ptr(), tiles_per_wg, 1, st)  # producer writes X
+                lib.ub3_stream(GRID, X.data_ptr(), tiles_per_wg, wmode, st)  # producer writes X
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(); lib.ub3_stream(GRID, src.data_ptr(), tiles_per_wg, 0, st); e1.record()
                 torch.cuda.synchronize()

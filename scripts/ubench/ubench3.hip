@@ -132,7 +132,10 @@ __global__ __launch_bounds__(512) void ub3_stream_kernel(v4i* buf, long tiles_pe
   unsigned acc = 0;
   for (long t = wave; t < tiles_per_wg; t += 8) {
     v4i* tile = base + t * 128;
-    if (write) {
+    if (write == 2) {          // normal-policy stores (stay in the XCD's write-back L2 until evicted)
+      tile[lane] = pattern(blockIdx.x, (unsigned)t, wave, lane);
+      tile[64 + lane] = pattern(blockIdx.x, (unsigned)t, wave, 64 + lane);
+    } else if (write) {
       __builtin_nontemporal_store(pattern(blockIdx.x, (unsigned)t, wave, lane), tile + lane);
       __builtin_nontemporal_store(pattern(blockIdx.x, (unsigned)t, wave, 64 + lane), tile + 64 + lane);
     } else {

@@ -212,13 +212,7 @@ class Engine:
         self._partials = None
         self._bpartials = None
         self._masks = None
-        # launch order of the product pairs (grid y): the widest first, the narrow ones (9-10 tiles per block, half the duration of a
-        # 16-18-tile workgroup) last, so that the tail of every weight-gradient launch is made of short workgroups
-        pairs = PK.region_local_pairs(self.dl.lay)
-        order = np.argsort(-(pairs[:, 1] + pairs[:, 3]), kind="stable")
-        if os.environ.get("AVC_WG_PAIR_ORDER") == "layout":
-            order = np.arange(len(pairs))
-        self._pairs_host = np.ascontiguousarray(pairs[order])
+        self._pairs_host = PK.region_local_pairs(self.dl.lay)   # (launch order = layout order; widest-first measured the same: 40.5 ms)
         self._sdf_bias0 = int(self.dl.lay.pbase["sdf.b%d" % (spec.NMID + 2)])   # flat index of bias[0] of the last SDF layer
         self._packed_key = None
         self._packed = None

@@ -31,13 +31,16 @@ def pack_weight(w: torch.Tensor) -> torch.Tensor:
     return p.to(torch.bfloat16).reshape(-1)
 
 
+LIBRARY_GEMM = os.environ.get("AVC_VIT_LIBRARY_GEMM") == "1"   # see _linear_raw
+
+
 class _Lin:
     def __init__(self, w, b, dev):
         w = w.float().to(dev)
         self.N, self.K = w.shape
         self.wp = pack_weight(w)
         self.wtp = pack_weight(w.t().contiguous())
-        self.wd = w.to(torch.bfloat16)        # dense copy for the large-M library GEMM (batched scoring, row f-4)
+        self.wd = w.to(torch.bfloat16) if LIBRARY_GEMM else None   # dense copy for the library-GEMM comparison path only
         self.b = None if b is None else b.float().to(dev).contiguous()
 
 
@@ -52,7 +55,9 @@ def _ws(device, nbytes):
     return _workspace[key]
 
 
-BIG_M = 192   # rows from which a linear goes to the library GEMM instead of the M <= 128 latency kernel (B >= 4 images)
+BIG_M = 192   # rows from which a call counts as "batched" (B >= 4 images): the kernel then takes groups of 4 row tiles per workgroup
+# AVC_VIT_LIBRARY_GEMM=1 (LIBRARY_GEMM above): batched calls go to the library GEMM (torch.mm -> hipBLASLt) instead of the
+# hand-written kernel -- the comparison point of the batched scoring path (ShapeGen codebook search, pose retrieval), not the default
 
 
 def _gelu_grad(pre):
@@ -66,11 +71,9 @@ def _linear_raw(x2d, lin, transposed, bias, residual, act, want_pre, gelu_pre=No
     lib = L.load()
     M = x2d.shape[0]
     N, K = (lin.K, lin.N) if transposed else (lin.N, lin.K)
-    if M >= BIG_M:
+    if LIBRARY_GEMM and M >= BIG_M:
         if gelu_pre is not None:
             x2d = x2d * _gelu_grad(gelu_pre)
-        # batched scoring (ShapeGen codebook, pose retrieval: hundreds of renders per call): a plain GEMM, where hipBLASLt is the
-        # right tool; the hand-written kernel streams the weights once per 128 rows
         w = lin.wd if transposed else lin.wd.t()
         y = torch.mm(x2d.to(torch.bfloat16), w, out_dtype=torch.float32)
         if bias is not None:
@@ -85,16 +88,13 @@ def _linear_raw(x2d, lin, transposed, bias, residual, act, want_pre, gelu_pre=No
     wp = lin.wtp if transposed else lin.wp
     y = torch.empty(M, N, device=x2d.device, dtype=torch.float32)
     pre = torch.empty_like(y) if (act and want_pre) else None
-    ws = _ws(x2d.device, lib.avc_vit_workspace_bytes(min(M, 128), K))
-    for m0 in range(0, M, 128):
-        m1 = min(M, m0 + 128)
-        off = lambda t, cols: None if t is None else t.data_ptr() + m0 * cols * 4
-        if gelu_pre is not None:
-            L.check(lib.avc_vit_linear_bwd_gelu(off(x2d, K), off(gelu_pre, K), L.ptr(wp), off(y, N), m1 - m0, N, K, L.ptr(ws), L.stream()),
-                    "avc_vit_linear_bwd_gelu")
-            continue
-        L.check(lib.avc_vit_linear(off(x2d, K), L.ptr(wp), L.ptr(bias), off(residual, N), off(y, N), off(pre, N),
-                                   m1 - m0, N, K, act, L.ptr(ws), L.stream()), "avc_vit_linear")
+    ws = _ws(x2d.device, lib.avc_vit_workspace_bytes(M, K))
+    if gelu_pre is not None:
+        L.check(lib.avc_vit_linear_bwd_gelu(L.ptr(x2d), L.ptr(gelu_pre), L.ptr(wp), L.ptr(y), M, N, K, L.ptr(ws), L.stream()),
+                "avc_vit_linear_bwd_gelu")
+    else:
+        L.check(lib.avc_vit_linear(L.ptr(x2d), L.ptr(wp), L.ptr(bias), L.ptr(residual), L.ptr(y), L.ptr(pre), M, N, K, act, L.ptr(ws),
+                                   L.stream()), "avc_vit_linear")
     return y, pre
 
 

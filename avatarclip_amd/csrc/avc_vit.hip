@@ -9,7 +9,7 @@
 #include "avc_common.h"
 #include "../../include/avc.h"
 
-#define VIT_MAX_MT 4   // up to 128 rows (tokens) per launch
+#define VIT_MAX_MT 4   // up to 128 rows (tokens): the per-iteration latency path (one row tile per workgroup); more rows: groups of 4
 #define VIT_WAVES 8    // wavefronts per workgroup = K-split factor
 
 // X[M,K] fp32 -> bf16 A-operand fragments [m-tile][k-step][lane][8] (lane (i,h) holds X[32m+i][16s+8h+j]): the GEMM then
@@ -60,12 +60,13 @@ __global__ __launch_bounds__(64 * VIT_WAVES) void vit_linear_kernel(const b8* __
   const int n = lane & 31, h = lane >> 5;
   const int t = blockIdx.x;           // output column tile
   const int KS = K >> 4;              // k-steps of 16
-  // gridDim.y > 1: this workgroup owns ONE 32-row tile (blockIdx.y) of the rows instead of all of them -- it then reads a quarter of
-  // the packed activations (the K = 3072 linears re-read 768 KB of them per workgroup from L2 otherwise: 35 us) and the four
-  // workgroups that share a weight tile sit on one XCD (block id = x + gridDim.x * y, gridDim.x a multiple of 8), i.e. share its L2
+  // blockIdx.y = group of MT 32-row tiles of the rows.  Per-iteration calls (M <= 128 rows): MT = 1, one workgroup per (column tile,
+  // row tile) -- it then reads a quarter of the packed activations (the K = 3072 linears re-read 768 KB of them per workgroup from
+  // L2 otherwise: 35 us) and the four workgroups that share a weight tile sit on one XCD (block id = x + gridDim.x * y, gridDim.x a
+  // multiple of 8), i.e. share its L2.  Batched scoring (hundreds of images): MT = 4, a weight fragment feeds four MFMAs.
   const int mb = blockIdx.y;
-  Xs += (long)mb * KS * 64;
-  const int row0 = 32 * mb;
+  Xs += (long)mb * MT * KS * 64;
+  const int row0 = 32 * MT * mb;
   facc acc[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
@@ -108,40 +109,33 @@ __global__ __launch_bounds__(64 * VIT_WAVES) void vit_linear_kernel(const b8* __
 }
 
 extern "C" long avc_vit_workspace_bytes(int M, int K) {
-  const long mt = (M + 31) / 32;
+  const long mt = ((M + 127) / 128) * 4;   // whole groups of 4 row tiles (the rows past M are packed as zeros)
   return mt * (K / 16) * 1024L;
 }
 
 static int vit_linear_impl(const float* x, const float* x_gelu_pre, const void* w_packed, const float* bias, const float* residual,
                            float* y, float* y_pre, int M, int N, int K, int act, void* workspace, void* stream) {
   if (M <= 0) return 0;
-  if ((N & 31) || (K & 15) || M > 32 * VIT_MAX_MT) {
-    avc_set_error("avc_vit_linear: need N % 32 == 0, K % 16 == 0, M <= 128");
+  if ((N & 31) || (K & 15)) {
+    avc_set_error("avc_vit_linear: need N % 32 == 0, K % 16 == 0");
     return 1;
   }
   if (!workspace) { avc_set_error("avc_vit_linear: workspace == NULL (avc_vit_workspace_bytes)"); return 1; }
   hipStream_t s = (hipStream_t)stream;
   const int mt = (M + 31) / 32;
+  const bool batched = mt > VIT_MAX_MT;                 // more than 128 rows: groups of 4 row tiles per workgroup
+  const int mt_packed = batched ? ((mt + 3) / 4) * 4 : mt;
   b8* xs = (b8*)workspace;
-  hipLaunchKernelGGL(vit_pack_x_kernel, dim3(K / 16, mt), dim3(64), 0, s, x, x_gelu_pre, xs, M, K);
-#ifndef VIT_SPLIT_M
-#define VIT_SPLIT_M 1
-#endif
-  const bool split_m = VIT_SPLIT_M && mt > 1;
-  const dim3 grid(N / 32, split_m ? mt : 1), block(64 * VIT_WAVES);
+  hipLaunchKernelGGL(vit_pack_x_kernel, dim3(K / 16, mt_packed), dim3(64), 0, s, x, x_gelu_pre, xs, M, K);
+  const dim3 grid(N / 32, batched ? mt_packed / 4 : mt), block(64 * VIT_WAVES);
   const b8* wp = (const b8*)w_packed;
-  const int lds = VIT_WAVES * (split_m ? 1 : mt) * 4096;
+  const int lds = VIT_WAVES * (batched ? 4 : 1) * 4096;
   static unsigned long long attr_seen = 0;
   if (avc_first_use_on_device(attr_seen)) {
-    (void)hipFuncSetAttribute((const void*)vit_linear_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, VIT_WAVES * 3 * 4096);
     (void)hipFuncSetAttribute((const void*)vit_linear_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, VIT_WAVES * 4 * 4096);
   }
-  switch (split_m ? 1 : mt) {
-    case 1: hipLaunchKernelGGL((vit_linear_kernel<1>), grid, block, lds, s, xs, wp, bias, residual, y, y_pre, M, N, K, act); break;
-    case 2: hipLaunchKernelGGL((vit_linear_kernel<2>), grid, block, lds, s, xs, wp, bias, residual, y, y_pre, M, N, K, act); break;
-    case 3: hipLaunchKernelGGL((vit_linear_kernel<3>), grid, block, lds, s, xs, wp, bias, residual, y, y_pre, M, N, K, act); break;
-    default: hipLaunchKernelGGL((vit_linear_kernel<4>), grid, block, lds, s, xs, wp, bias, residual, y, y_pre, M, N, K, act); break;
-  }
+  if (batched) hipLaunchKernelGGL((vit_linear_kernel<4>), grid, block, lds, s, xs, wp, bias, residual, y, y_pre, M, N, K, act);
+  else hipLaunchKernelGGL((vit_linear_kernel<1>), grid, block, lds, s, xs, wp, bias, residual, y, y_pre, M, N, K, act);
   return avc_check_launch("avc_vit_linear");
 }
 

@@ -108,6 +108,81 @@ __global__ __launch_bounds__(64 * VIT_WAVES) void vit_linear_kernel(const b8* __
   }
 }
 
+// Batched calls (hundreds of images: ShapeGen codebook search, pose retrieval -- row f-4): a plain tiled GEMM.  One 4-wavefront
+// workgroup per 128 x 128 output block, every wavefront a 64 x 64 quarter of it (2 x 2 MFMA tiles: each fragment it loads feeds two
+// MFMAs, 1 KiB of operands per MFMA; the two wavefronts that share a row / column pair meet in the CU's L1), the whole K range per
+// wavefront (no split-K, no LDS), fragments prefetched VIT_GEMM_AHEAD k-steps ahead.  Both operands arrive pre-packed in fragment
+// order, so every load is one coalesced 16 B per lane.
+#ifndef VIT_GEMM_AHEAD
+#define VIT_GEMM_AHEAD 3
+#endif
+__global__ __launch_bounds__(256) void vit_gemm_kernel(const b8* __restrict__ Xs, const b8* __restrict__ Wp, const float* __restrict__ bias,
+                                                       const float* __restrict__ res, float* __restrict__ Y, float* __restrict__ Ypre,
+                                                       int M, int N, int K, int act) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int n = lane & 31, h = lane >> 5;
+  const int KS = K >> 4;
+  const int mt0 = 4 * blockIdx.y + 2 * (wv & 1), nt0 = 4 * blockIdx.x + 2 * (wv >> 1);
+  const b8* xa = Xs + (long)mt0 * KS * 64 + lane;
+  const b8* wb = Wp + (long)nt0 * KS * 64 + lane;
+  const long xstep = (long)KS * 64;     // next row / column tile
+  facc acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  b8 fx[VIT_GEMM_AHEAD][2], fw[VIT_GEMM_AHEAD][2];
+#pragma unroll
+  for (int d = 0; d < VIT_GEMM_AHEAD; ++d) {
+    if (d < KS) {
+      fx[d][0] = xa[(long)d * 64]; fx[d][1] = xa[xstep + (long)d * 64];
+      fw[d][0] = wb[(long)d * 64]; fw[d][1] = wb[xstep + (long)d * 64];
+    }
+  }
+  for (int s0 = 0; s0 < KS; s0 += VIT_GEMM_AHEAD) {
+#pragma unroll
+    for (int d = 0; d < VIT_GEMM_AHEAD; ++d) {
+      const int s = s0 + d;
+      if (s < KS) {
+        const b8 x0 = fx[d][0], x1 = fx[d][1], w0 = fw[d][0], w1 = fw[d][1];
+        const int sn = s + VIT_GEMM_AHEAD;
+        if (sn < KS) {
+          fx[d][0] = xa[(long)sn * 64]; fx[d][1] = xa[xstep + (long)sn * 64];
+          fw[d][0] = wb[(long)sn * 64]; fw[d][1] = wb[xstep + (long)sn * 64];
+        }
+        acc[0][0] = MF<b8>::mma(x0, w0, acc[0][0]);
+        acc[0][1] = MF<b8>::mma(x0, w1, acc[0][1]);
+        acc[1][0] = MF<b8>::mma(x1, w0, acc[1][0]);
+        acc[1][1] = MF<b8>::mma(x1, w1, acc[1][1]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = 32 * (nt0 + j) + n;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * (mt0 + i) + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < M) {
+          float v = acc[i][j][r] + bv;
+          const long o = (long)row * N + col;
+          if (act == 1) {
+            if (Ypre) Ypre[o] = v;
+            v = v * sigmoidf_(1.702f * v);
+          }
+          if (res) v += res[o];
+          Y[o] = v;
+        }
+      }
+    }
+  }
+}
+
 extern "C" long avc_vit_workspace_bytes(int M, int K) {
   const long mt = ((M + 127) / 128) * 4;   // whole groups of 4 row tiles (the rows past M are packed as zeros)
   return mt * (K / 16) * 1024L;
@@ -134,8 +209,16 @@ static int vit_linear_impl(const float* x, const float* x_gelu_pre, const void* 
   if (avc_first_use_on_device(attr_seen)) {
     (void)hipFuncSetAttribute((const void*)vit_linear_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, VIT_WAVES * 4 * 4096);
   }
-  if (batched) hipLaunchKernelGGL((vit_linear_kernel<4>), grid, block, lds, s, xs, wp, bias, residual, y, y_pre, M, N, K, act);
-  else hipLaunchKernelGGL((vit_linear_kernel<1>), grid, block, lds, s, xs, wp, bias, residual, y, y_pre, M, N, K, act);
+#ifndef VIT_BATCHED_GEMM
+#define VIT_BATCHED_GEMM 1   // 0: batched calls through the split-K latency kernel with 4 row tiles per workgroup (13.5 k images/s at B = 512)
+#endif
+  if (batched && VIT_BATCHED_GEMM && (N & 127) == 0) {
+    hipLaunchKernelGGL(vit_gemm_kernel, dim3(N / 128, mt_packed / 4), dim3(256), 0, s, xs, wp, bias, residual, y, y_pre, M, N, K, act);
+  } else if (batched) {
+    hipLaunchKernelGGL((vit_linear_kernel<4>), grid, block, lds, s, xs, wp, bias, residual, y, y_pre, M, N, K, act);
+  } else {
+    hipLaunchKernelGGL((vit_linear_kernel<1>), grid, block, lds, s, xs, wp, bias, residual, y, y_pre, M, N, K, act);
+  }
   return avc_check_launch("avc_vit_linear");
 }
 

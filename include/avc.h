@@ -143,7 +143,8 @@ int avc_mc_emit(const float* u, int nx, int ny, int nz, float iso, const int* vf
  * y[M,N] = act(x[M,K] W^T + bias) (+ residual); W pre-packed bf16 [N/32][K/16][64][8] (lane (n,h): W[32t+n][16s+8h+j]).
  * act 1 = QuickGELU (y_pre, if given, receives the pre-activation for the backward).  The backward dX = dY W is the same
  * call with the packed W^T (weights are frozen in AvatarCLIP: main.py:260).  Any M: up to 128 rows (the per-iteration calls) one
- * workgroup per (32 columns, 32 rows); beyond (batched scoring) per (32 columns, 128 rows). */
+ * 8-wavefront split-K workgroup per (32 columns, 32 rows); beyond (batched scoring) a tiled GEMM, one 4-wavefront workgroup per
+ * 128 x 128 output block (N % 128 == 0). */
 int avc_vit_linear(const float* x, const void* w_packed, const float* bias, const float* residual, float* y,
                    float* y_pre, int M, int N, int K, int act, void* workspace /* avc_vit_workspace_bytes(M, K) */,
                    void* stream);

@@ -211,13 +211,14 @@ def test_real_openai_weights_when_supplied():
 
 @gpu
 def test_batched_scoring_path_matches_the_per_pair_path():
-    """row f-4 (ShapeGen codebook search / pose retrieval: hundreds of renders per encode_image call): from 512 rows on the linears
-    go to the library GEMM; the embeddings must agree with the M <= 128 kernel path image by image, and with the oracle"""
+    """row f-4 (ShapeGen codebook search / pose retrieval: hundreds of renders per encode_image call): above 128 token rows the
+    linears run in the tiled GEMM kernel (vit_gemm_kernel); the embeddings must agree with the M <= 128 latency-kernel path image by
+    image, and with the oracle"""
     from avatarclip_amd import clip_vit as V
     sd = C.random_state_dict(0)
     model = V.ClipVisionB32(sd, torch.device("cuda"))
     g = torch.Generator().manual_seed(7)
-    img = torch.randn(12, 3, 224, 224, generator=g)          # 12 x 50 = 600 token rows >= BIG_M
+    img = torch.randn(12, 3, 224, 224, generator=g)          # 12 x 50 = 600 token rows: the batched kernel (> 128 rows)
     assert 12 * V.TOKENS >= V.BIG_M
     big = model.encode_image(img.cuda()).float().cpu()
     small = torch.cat([model.encode_image(img[i:i + 2].cuda()).float().cpu() for i in range(0, 12, 2)])

@@ -430,8 +430,16 @@ __global__ __launch_bounds__(64 * AT_PARTS) void vit_attn_bwd_kernel(const float
   for (int c = 0; c < AT_COLS; ++c) { dqp[c] = dq[c]; dqp[Wd + c] = dk[c]; dqp[2 * Wd + c] = dv[c]; }
 }
 
+// matrix-core attention (avc_vit_attn.hip); VIT_ATTN_MFMA=0 keeps the fp32 VALU kernels above (the A/B of profiles/r03_ab_kernels.txt)
+#ifndef VIT_ATTN_MFMA
+#define VIT_ATTN_MFMA 1
+#endif
+int avc_attn_fwd_mfma(const float* qkv, float* out, int B, int width, int heads, void* stream);
+int avc_attn_bwd_mfma(const float* qkv, const float* dout, float* dqkv, int B, int width, int heads, void* stream);
+
 extern "C" int avc_vit_attention_fwd(const float* qkv, float* out, int B, int T, int width, int heads, void* stream) {
   if (T != AT_T || width != heads * AT_D) { avc_set_error("avc_vit_attention: built for 50 tokens, head dim 64"); return 1; }
+  if (VIT_ATTN_MFMA) return avc_attn_fwd_mfma(qkv, out, B, width, heads, stream);
   hipLaunchKernelGGL(vit_attn_fwd_kernel, dim3(B * heads), dim3(64 * AT_PARTS), 0, (hipStream_t)stream, qkv, out, width, heads, 0.125f);
   return avc_check_launch("avc_vit_attention_fwd");
 }
@@ -450,6 +458,7 @@ extern "C" int avc_text_attention_fwd(const float* qkv, float* out, int B, int T
 extern "C" int avc_vit_attention_bwd(const float* qkv, const float* dout, float* dqkv, int B, int T, int width, int heads,
                                      void* stream) {
   if (T != AT_T || width != heads * AT_D) { avc_set_error("avc_vit_attention: built for 50 tokens, head dim 64"); return 1; }
+  if (VIT_ATTN_MFMA) return avc_attn_bwd_mfma(qkv, dout, dqkv, B, width, heads, stream);
   const size_t lds = (4 * AT_T * AT_LD + 2 * AT_T * (AT_T + 1) + 3 * AT_PARTS * 64) * sizeof(float);
   static unsigned long long attr_seen = 0;
   if (avc_first_use_on_device(attr_seen)) {

@@ -27,6 +27,25 @@ template <class N> static inline bool offsets_match(const int* offs) {
   return true;
 }
 
+// Static issue priority per wavefront (s_setprio once, before the main loop).  The wavefronts w, w + 4 (, w + 8) of a workgroup share a
+// SIMD and run the same instruction sequence between the same barriers; between equals the arbiter prefers the OLDER wave, i.e. the
+// later-dispatched ones lose every contested VALU slot.  AVC_WAVE_PRIO: 0 = leave it to age, 1 = the younger half of the workgroup
+// at priority 1, 2 = priority w / 4, 3 = the older half at priority 1.  (Measured: profiles/r03_ab_kernels.txt.)
+#ifndef AVC_WAVE_PRIO
+#define AVC_WAVE_PRIO 0
+#endif
+__device__ __forceinline__ void avc_static_wave_priority() {
+#if AVC_WAVE_PRIO == 1
+  if ((threadIdx.x >> 6) >= (blockDim.x >> 7)) __builtin_amdgcn_s_setprio(1);
+#elif AVC_WAVE_PRIO == 2
+  const int q = threadIdx.x >> 8;
+  if (q == 1) __builtin_amdgcn_s_setprio(1);
+  if (q >= 2) __builtin_amdgcn_s_setprio(2);
+#elif AVC_WAVE_PRIO == 3
+  if ((threadIdx.x >> 6) < (blockDim.x >> 7)) __builtin_amdgcn_s_setprio(1);
+#endif
+}
+
 struct PointSrc {
   const float* pts;      // [N,3] or nullptr -> ray mode
   const float* rays_o;   // [R,3]

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
   constexpr AvcOffsets o = Off<N>::value;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   typedef StageT<BWD_G> ST;
+  avc_static_wave_priority();
   const int lane0 = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const long nblk = (npts + 31) >> 5;

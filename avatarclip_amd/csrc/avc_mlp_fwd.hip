@@ -56,6 +56,7 @@ __global__ __launch_bounds__(64 * SDF_WPB) void mlp_sdf_kernel(PointSrc ps, long
   constexpr AvcOffsets o = Off<N>::value;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   typedef StageT<FWD_G> ST;
+  avc_static_wave_priority();
   const int lane = threadIdx.x & 63;
   const int h = lane >> 5;
   const int p = lane & 31;
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
   typedef typename std::conditional<TRAIN, PanelLayout<N>, ScratchLayout<N>>::type L;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   typedef StageT<FWD_G> ST;
+  avc_static_wave_priority();
   const int lane0 = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const long nblk = (npts + 31) >> 5;

@@ -104,7 +104,9 @@ class LinearFn(torch.autograd.Function):
         shp = x.shape
         x2 = x.reshape(-1, lin.K).contiguous().float()
         r2 = None if residual is None else residual.reshape(-1, lin.N).contiguous().float()
-        y, pre = _linear_raw(x2, lin, False, lin.b, r2, act, True)
+        # the pre-activation of a QuickGELU layer is only kept for the backward pass (scoring calls run under no_grad: one 4-byte
+        # store per output element less)
+        y, pre = _linear_raw(x2, lin, False, lin.b, r2, act, bool(act) and ctx.needs_input_grad[0])
         ctx.lin, ctx.act, ctx.has_res = lin, act, residual is not None
         if pre is not None:          # (nothing to save for a linear without activation: a dummy tensor would cost a fill launch per call)
             ctx.save_for_backward(pre)

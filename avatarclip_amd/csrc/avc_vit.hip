@@ -183,6 +183,13 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(const b8* __restrict__ Xs
   }
 }
 
+// batched calls: the LDS-staged GEMM of avc_vit_gemm.hip (128 x 128 blocks)
+bool avc_vit_gemm_lds(const void* xs, const void* wp, const float* bias, const float* res, float* y, float* y_pre, int M, int N, int K,
+                      int act, int mt_packed, void* stream);
+#ifndef VIT_GEMM_LDS
+#define VIT_GEMM_LDS 1   // 0: the direct-from-L1 128 x 128 kernel above (the A/B of profiles/r03_score_bench.txt)
+#endif
+
 extern "C" long avc_vit_workspace_bytes(int M, int K) {
   const long mt = ((M + 127) / 128) * 4;   // whole groups of 4 row tiles (the rows past M are packed as zeros)
   return mt * (K / 16) * 1024L;
@@ -212,7 +219,8 @@ static int vit_linear_impl(const float* x, const float* x_gelu_pre, const void* 
 #ifndef VIT_BATCHED_GEMM
 #define VIT_BATCHED_GEMM 1   // 0: batched calls through the split-K latency kernel with 4 row tiles per workgroup (13.5 k images/s at B = 512)
 #endif
-  if (batched && VIT_BATCHED_GEMM && (N & 127) == 0) {
+  if (batched && VIT_BATCHED_GEMM && VIT_GEMM_LDS && avc_vit_gemm_lds(xs, wp, bias, residual, y, y_pre, M, N, K, act, mt_packed, stream)) {
+  } else if (batched && VIT_BATCHED_GEMM && (N & 127) == 0) {
     hipLaunchKernelGGL(vit_gemm_kernel, dim3(N / 128, mt_packed / 4), dim3(256), 0, s, xs, wp, bias, residual, y, y_pre, M, N, K, act);
   } else if (batched) {
     hipLaunchKernelGGL((vit_linear_kernel<4>), grid, block, lds, s, xs, wp, bias, residual, y, y_pre, M, N, K, act);

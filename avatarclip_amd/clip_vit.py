@@ -32,6 +32,7 @@ def pack_weight(w: torch.Tensor) -> torch.Tensor:
 
 
 LIBRARY_GEMM = os.environ.get("AVC_VIT_LIBRARY_GEMM") == "1"   # see _linear_raw
+PACKED_PIPELINE = os.environ.get("AVC_VIT_PACKED", "1") != "0"   # see ClipVisionB32._encode_image_batched
 
 
 class _Lin:
@@ -174,6 +175,7 @@ class ClipVisionB32:
         # the text tower is built on demand from the same state dict (clip_text.ClipTextB32) when it carries one
         self._text_sd = state_dict if "token_embedding.weight" in state_dict else None
         self._text = None
+        self._packed = {}
 
     def eval(self):
         return self
@@ -184,8 +186,51 @@ class ClipVisionB32:
     def cuda(self):
         return self
 
+    def _packed_buf(self, tag, M, K):
+        """a packed bf16 activation buffer of the batched pipeline (one per role, grown on demand, stream-ordered reuse)"""
+        need = L.load().avc_vit_workspace_bytes(M, K)
+        buf = self._packed.get(tag)
+        if buf is None or buf.numel() < need:
+            buf = self._packed[tag] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return buf
+
+    @torch.no_grad()
+    def _encode_image_batched(self, image: torch.Tensor) -> torch.Tensor:
+        """encode_image for scoring calls (no gradient, 3+ images: ShapeGen/main.py:104-128, pose_generation.py:79-110): the same
+        arithmetic as the autograd path below (bf16 GEMM operands, fp32 accumulation, fp32 residual stream and LayerNorm
+        statistics), with the activations handed from kernel to kernel as packed bf16 operands -- LayerNorm writes the operand of
+        the linear behind it, attention that of the out-projection, c_fc + QuickGELU that of c_proj -- instead of fp32 rows and a
+        packing pass in front of every linear."""
+        lib, st = L.load(), L.stream()
+        B = image.shape[0]
+        x = image.float().reshape(B, 3, RES // PATCH, PATCH, RES // PATCH, PATCH).permute(0, 2, 4, 1, 3, 5)
+        x = x.reshape(B, (RES // PATCH) ** 2, 3 * PATCH * PATCH)
+        x = LinearFn.apply(x, self.conv, 0, None)
+        x = torch.cat([self.cls.expand(B, 1, WIDTH), x], dim=1) + self.pos
+        x = F.layer_norm(x, (WIDTH,), self.ln_pre[0], self.ln_pre[1], 1e-5).reshape(B * TOKENS, WIDTH).contiguous()
+        M = B * TOKENS
+        a768, b768, a3072 = self._packed_buf("ln", M, WIDTH), self._packed_buf("attn", M, WIDTH), self._packed_buf("fc", M, 4 * WIDTH)
+        qkv = torch.empty(M, 3 * WIDTH, device=x.device, dtype=torch.float32)
+        x2 = torch.empty_like(x)
+        for blk in self.blocks:
+            L.check(lib.avc_vit_ln_pack(L.ptr(x), L.ptr(blk["ln1"][0]), L.ptr(blk["ln1"][1]), 1e-5, M, WIDTH, L.ptr(a768), st), "avc_vit_ln_pack")
+            L.check(lib.avc_vit_linear_packed(L.ptr(a768), L.ptr(blk["qkv"].wp), L.ptr(blk["qkv"].b), None, L.ptr(qkv), None,
+                                              M, 3 * WIDTH, WIDTH, 0, st), "avc_vit_linear_packed")
+            L.check(lib.avc_vit_attention_fwd_packed(L.ptr(qkv), L.ptr(b768), B, TOKENS, WIDTH, HEADS, st), "avc_vit_attention_fwd_packed")
+            L.check(lib.avc_vit_linear_packed(L.ptr(b768), L.ptr(blk["out"].wp), L.ptr(blk["out"].b), L.ptr(x), L.ptr(x2), None,
+                                              M, WIDTH, WIDTH, 0, st), "avc_vit_linear_packed")
+            L.check(lib.avc_vit_ln_pack(L.ptr(x2), L.ptr(blk["ln2"][0]), L.ptr(blk["ln2"][1]), 1e-5, M, WIDTH, L.ptr(a768), st), "avc_vit_ln_pack")
+            L.check(lib.avc_vit_linear_packed(L.ptr(a768), L.ptr(blk["fc"].wp), L.ptr(blk["fc"].b), None, None, L.ptr(a3072),
+                                              M, 4 * WIDTH, WIDTH, 1, st), "avc_vit_linear_packed")
+            L.check(lib.avc_vit_linear_packed(L.ptr(a3072), L.ptr(blk["proj"].wp), L.ptr(blk["proj"].b), L.ptr(x2), L.ptr(x), None,
+                                              M, WIDTH, 4 * WIDTH, 0, st), "avc_vit_linear_packed")
+        x = F.layer_norm(x.reshape(B, TOKENS, WIDTH)[:, 0, :], (WIDTH,), self.ln_post[0], self.ln_post[1], 1e-5)
+        return LinearFn.apply(x, self.proj, 0, None)
+
     def encode_image(self, image: torch.Tensor) -> torch.Tensor:
         B = image.shape[0]
+        if PACKED_PIPELINE and B * TOKENS > 128 and not LIBRARY_GEMM and not (torch.is_grad_enabled() and image.requires_grad):
+            return self._encode_image_batched(image)
         # conv1 (32x32, stride 32, no bias) == GEMM over flattened patches in (c, ky, kx) order
         x = image.float().reshape(B, 3, RES // PATCH, PATCH, RES // PATCH, PATCH).permute(0, 2, 4, 1, 3, 5)
         x = x.reshape(B, (RES // PATCH) ** 2, 3 * PATCH * PATCH)

@@ -184,8 +184,8 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(const b8* __restrict__ Xs
 }
 
 // batched calls: the LDS-staged GEMM of avc_vit_gemm.hip (128 x 128 blocks)
-bool avc_vit_gemm_lds(const void* xs, const void* wp, const float* bias, const float* res, float* y, float* y_pre, int M, int N, int K,
-                      int act, int mt_packed, void* stream);
+bool avc_vit_gemm_lds(const void* xs, const void* wp, const float* bias, const float* res, float* y, float* y_pre, void* ys, int M, int N,
+                      int K, int act, int mt_packed, void* stream);
 #ifndef VIT_GEMM_LDS
 #define VIT_GEMM_LDS 1   // 0: the direct-from-L1 128 x 128 kernel above (the A/B of profiles/r03_score_bench.txt)
 #endif
@@ -219,7 +219,7 @@ static int vit_linear_impl(const float* x, const float* x_gelu_pre, const void* 
 #ifndef VIT_BATCHED_GEMM
 #define VIT_BATCHED_GEMM 1   // 0: batched calls through the split-K latency kernel with 4 row tiles per workgroup (13.5 k images/s at B = 512)
 #endif
-  if (batched && VIT_BATCHED_GEMM && VIT_GEMM_LDS && avc_vit_gemm_lds(xs, wp, bias, residual, y, y_pre, M, N, K, act, mt_packed, stream)) {
+  if (batched && VIT_BATCHED_GEMM && VIT_GEMM_LDS && avc_vit_gemm_lds(xs, wp, bias, residual, y, y_pre, nullptr, M, N, K, act, mt_packed, stream)) {
   } else if (batched && VIT_BATCHED_GEMM && (N & 127) == 0) {
     hipLaunchKernelGGL(vit_gemm_kernel, dim3(N / 128, mt_packed / 4), dim3(256), 0, s, xs, wp, bias, residual, y, y_pre, M, N, K, act);
   } else if (batched) {
@@ -237,6 +237,75 @@ extern "C" int avc_vit_linear(const float* x, const void* w_packed, const float*
 extern "C" int avc_vit_linear_bwd_gelu(const float* dy, const float* pre, const void* wt_packed, float* dx, int M, int N, int K,
                                        void* workspace, void* stream) {
   return vit_linear_impl(dy, pre, wt_packed, nullptr, nullptr, dx, nullptr, M, N, K, 0, workspace, stream);
+}
+
+// ---- the batched no-grad pipeline (scoring): activations stay packed bf16 between the kernels ----
+// LayerNorm (fp32 statistics, eps inside the square root like torch) of x[M,K] straight into the packed operand of the next linear.
+// One workgroup per 32-row tile: a wavefront normalises 8 rows into an LDS image of the tile, then the fragments go out whole.
+#define LNP_LD (768 + 8)
+__global__ __launch_bounds__(256) void vit_ln_pack_kernel(const float* __restrict__ X, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, b8* __restrict__ xs, int M) {
+  __shared__ __attribute__((aligned(16))) __bf16 tile[32][LNP_LD];
+  constexpr int K = 768, KS = K / 16;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, mt = blockIdx.x;
+  f4 g[3], bt[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    g[c] = *reinterpret_cast<const f4*>(gamma + 4 * (lane + 64 * c));
+    bt[c] = *reinterpret_cast<const f4*>(beta + 4 * (lane + 64 * c));
+  }
+  for (int q = 0; q < 8; ++q) {
+    const int i = 8 * wv + q, row = 32 * mt + i;
+    f4 v[3];
+    float s1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      v[c] = row < M ? *reinterpret_cast<const f4*>(X + (long)row * K + 4 * (lane + 64 * c)) : f4{0.f, 0.f, 0.f, 0.f};
+      s1 += v[c][0] + v[c][1] + v[c][2] + v[c][3];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s1 += __shfl_xor(s1, d);
+    const float mean = s1 * (1.f / K);
+    float s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const float dlt = v[c][u] - mean; s2 += dlt * dlt; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s2 += __shfl_xor(s2, d);
+    const float rstd = rsqrtf(s2 * (1.f / K) + eps);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+      bf4 o;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) o[u] = (__bf16)((v[c][u] - mean) * rstd * g[c][u] + bt[c][u]);
+      *reinterpret_cast<bf4*>(&tile[i][4 * (lane + 64 * c)]) = o;
+    }
+  }
+  __syncthreads();
+  const int n = lane & 31, h = lane >> 5;
+  for (int s = wv; s < KS; s += 4) xs[((long)mt * KS + s) * 64 + lane] = *reinterpret_cast<const b8*>(&tile[n][16 * s + 8 * h]);
+}
+extern "C" int avc_vit_ln_pack(const float* x, const float* gamma, const float* beta, float eps, int M, int K, void* xs_packed,
+                               void* stream) {
+  if (K != 768) { avc_set_error("avc_vit_ln_pack: built for the ViT-B/32 width 768"); return 1; }
+  if (M <= 0) return 0;
+  const int mt = ((M + 127) / 128) * 4;          // the row-tile groups of avc_vit_workspace_bytes (rows past M: LayerNorm of zeros = beta)
+  hipLaunchKernelGGL(vit_ln_pack_kernel, dim3(mt), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps, (b8*)xs_packed, M);
+  return avc_check_launch("avc_vit_ln_pack");
+}
+// y = act(xs W^T + b) (+ residual) from an already packed operand (avc_vit_ln_pack, avc_vit_attention_fwd_packed or a previous
+// call's ys_packed); ys_packed != NULL: the result leaves as the packed operand of the next linear instead of fp32 rows
+extern "C" int avc_vit_linear_packed(const void* xs_packed, const void* w_packed, const float* bias, const float* residual, float* y,
+                                     void* ys_packed, int M, int N, int K, int act, void* stream) {
+  if (M <= 0) return 0;
+  const int mt_packed = ((M + 127) / 128) * 4;
+  if (!avc_vit_gemm_lds(xs_packed, w_packed, bias, residual, y, nullptr, ys_packed, M, N, K, act, mt_packed, stream)) {
+    avc_set_error("avc_vit_linear_packed: shape not covered (N % 128, K % 32, no residual / activation mix with a packed output)");
+    return 1;
+  }
+  return avc_check_launch("avc_vit_linear_packed");
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -444,6 +513,11 @@ __global__ __launch_bounds__(64 * AT_PARTS) void vit_attn_bwd_kernel(const float
 #endif
 int avc_attn_fwd_mfma(const float* qkv, float* out, int B, int width, int heads, void* stream);
 int avc_attn_bwd_mfma(const float* qkv, const float* dout, float* dqkv, int B, int width, int heads, void* stream);
+int avc_attn_fwd_mfma_packed(const float* qkv, void* out_packed, int B, int width, int heads, void* stream);
+extern "C" int avc_vit_attention_fwd_packed(const float* qkv, void* out_packed, int B, int T, int width, int heads, void* stream) {
+  if (T != AT_T || width != heads * AT_D) { avc_set_error("avc_vit_attention: built for 50 tokens, head dim 64"); return 1; }
+  return avc_attn_fwd_mfma_packed(qkv, out_packed, B, width, heads, stream);
+}
 
 extern "C" int avc_vit_attention_fwd(const float* qkv, float* out, int B, int T, int width, int heads, void* stream) {
   if (T != AT_T || width != heads * AT_D) { avc_set_error("avc_vit_attention: built for 50 tokens, head dim 64"); return 1; }

@@ -91,6 +91,9 @@ __device__ __forceinline__ void acc_to_b(const facc (&a)[2], float scale, b8 (&f
     for (int j = 0; j < 8; ++j) { f[2 * tj][j] = (bf)(a[tj][j] * scale); f[2 * tj + 1][j] = (bf)(a[tj][8 + j] * scale); }
 }
 
+// PACKED: `out` is the packed bf16 operand of the out-projection ([row tile][k-step][lane (row, half)][8 columns], rows = b * 50 +
+// token) instead of fp32 [B,T,W] -- the batched scoring pipeline (avc_vit_attention_fwd_packed)
+template <bool PACKED>
 __global__ __launch_bounds__(256) void vit_attn_fwd_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out, int Wd, int heads,
                                                                 float scale) {
   __shared__ __attribute__((aligned(16))) AtmMats m;
@@ -123,7 +126,35 @@ __global__ __launch_bounds__(256) void vit_attn_fwd_mfma_kernel(const float* __r
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) o = MF<b8>::mma(frag_perm(m.VT, 32 * td + n, s, h), pf[s], o);
-    if (i < ATM_T) {
+    if (PACKED) {
+      // this lane holds, for its query, d = 32 td + 8 q + 4 h + (0..3) in registers 4 q .. 4 q + 3; a packed chunk is 8 consecutive d
+      // (k-step 4 hd + 2 td + (q >> 1), half q & 1): lane half h assembles the chunks with (q & 1) == h from its own four values and
+      // the partner half's four
+      float mine[2][4], send[2][4], got[2][4];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          mine[e][u] = o[4 * (2 * e + h) + u];          // q = 2 e + h: stays
+          send[e][u] = o[4 * (2 * e + (1 - h)) + u];    // q = 2 e + (1 - h): the partner's chunk
+          got[e][u] = __shfl_xor(send[e][u], 32);
+        }
+      if (i < ATM_T) {
+        const long row = (long)b * ATM_T + i;
+        const long KSo = Wd >> 4;
+        b8* xs = reinterpret_cast<b8*>(out);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          b8 f;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            f[u] = (bf)(h == 0 ? mine[e][u] : got[e][u]);       // d = 8 q + 0..3 come from the h = 0 half
+            f[4 + u] = (bf)(h == 0 ? got[e][u] : mine[e][u]);   // d = 8 q + 4..7 from the h = 1 half
+          }
+          xs[((row >> 5) * KSo + 4 * hd + 2 * td + e) * 64 + (row & 31) + 32 * h] = f;
+        }
+      }
+    } else if (i < ATM_T) {
       float* op = out + ((long)b * ATM_T + i) * Wd + hd * ATM_D + 32 * td;
 #pragma unroll
       for (int r = 0; r < 16; ++r) op[acc_row(r, h)] = o[r];
@@ -225,8 +256,13 @@ __global__ __launch_bounds__(256) void vit_attn_bwd_mfma_kernel(const float* __r
 }
 
 int avc_attn_fwd_mfma(const float* qkv, float* out, int B, int width, int heads, void* stream) {
-  hipLaunchKernelGGL(vit_attn_fwd_mfma_kernel, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, qkv, out, width, heads, 0.125f);
+  hipLaunchKernelGGL(vit_attn_fwd_mfma_kernel<false>, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, qkv, out, width, heads, 0.125f);
   return avc_check_launch("avc_vit_attention_fwd");
+}
+int avc_attn_fwd_mfma_packed(const float* qkv, void* out_packed, int B, int width, int heads, void* stream) {
+  hipLaunchKernelGGL(vit_attn_fwd_mfma_kernel<true>, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, qkv, (float*)out_packed, width, heads,
+                     0.125f);
+  return avc_check_launch("avc_vit_attention_fwd_packed");
 }
 int avc_attn_bwd_mfma(const float* qkv, const float* dout, float* dqkv, int B, int width, int heads, void* stream) {
   const int lds = (int)sizeof(AtmMatsBwd);

@@ -39,10 +39,10 @@ __device__ __forceinline__ void g2_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");
 }
 
-template <int TM, int TN, int KB, int NST, int OCC, bool ACT, bool PRE, bool RES>
+template <int TM, int TN, int KB, int NST, int OCC, bool ACT, bool PRE, bool RES, bool PACK>
 __global__ __launch_bounds__(256, OCC) void vit_gemm_lds_kernel(const b8* __restrict__ Xs, const b8* __restrict__ Wp,
                                                            const float* __restrict__ bias, const float* __restrict__ res,
-                                                           float* __restrict__ Y, float* __restrict__ Ypre, int M, int N, int K) {
+                                                           float* __restrict__ Y, float* __restrict__ Ypre, b8* __restrict__ Ys, int M, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int AT = 2 * TM, BT = 2 * TN, FR = AT + BT;         // row tiles, column tiles, fragments per k-step of the block
   constexpr int CHUNKS = FR * KB;                             // 1-KiB DMA chunks per ring slot
@@ -114,6 +114,37 @@ __global__ __launch_bounds__(256, OCC) void vit_gemm_lds_kernel(const b8* __rest
     }
     if (++slot == NST) slot = 0;
   }
+  if (PACK) {
+    // the output as the NEXT linear's packed bf16 operand ([row tile][k-step][lane (row, half)][8 columns]) instead of fp32 rows:
+    // every wavefront turns its tiles round through its own 2-KiB corner of the (now idle) ring -- accumulator layout (lane =
+    // column, registers = rows) in, 16 bytes of one row out -- and stores whole 1-KiB fragments
+    __syncthreads();                                     // everybody is done reading the ring
+    __bf16* T = reinterpret_cast<__bf16*>(lds) + wv * (32 * 40);        // [32 rows][32 columns], row stride 40 (80 B: 16-B aligned, skewed)
+    const int KSo = N >> 4;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const long nt = nt_base + wn * TN + j;
+      const float bv = bias ? bias[32 * (int)nt + n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const long mt = mt_base + wm * TM + i;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r] + bv;
+          if (ACT) v = v * sigmoidf_(1.702f * v);
+          T[((r & 3) + 8 * (r >> 2) + 4 * h) * 40 + n] = (__bf16)v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {                    // the two k-steps of the next layer this 32-column tile covers
+          const b8 f = *reinterpret_cast<const b8*>(&T[n * 40 + 16 * e + 8 * h]);
+          Ys[((mt * KSo) + 2 * nt + e) * 64 + lane] = f;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = 32 * (int)(nt_base + wn * TN + j) + n;
@@ -141,28 +172,37 @@ __global__ __launch_bounds__(256, OCC) void vit_gemm_lds_kernel(const b8* __rest
 }
 
 template <int TM, int TN, int KB, int NST, int OCC>
-static void g2_launch(const b8* xs, const b8* wp, const float* bias, const float* res, float* y, float* y_pre, int M, int N, int K,
+static void g2_launch(const b8* xs, const b8* wp, const float* bias, const float* res, float* y, float* y_pre, b8* ys, int M, int N, int K,
                       int act, int mt_packed, hipStream_t s) {
   constexpr int lds = (2 * TM + 2 * TN) * KB * 1024 * NST;
+  static_assert(lds >= 4 * 32 * 40 * 2, "the pack-out epilogue borrows 2.5 KiB per wavefront");
   static unsigned long long attr_seen = 0;
+#define G2_K(A, P, R, Q) vit_gemm_lds_kernel<TM, TN, KB, NST, OCC, A, P, R, Q>
   if (avc_first_use_on_device(attr_seen)) {
-    (void)hipFuncSetAttribute((const void*)vit_gemm_lds_kernel<TM, TN, KB, NST, OCC, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void*)vit_gemm_lds_kernel<TM, TN, KB, NST, OCC, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void*)vit_gemm_lds_kernel<TM, TN, KB, NST, OCC, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void*)vit_gemm_lds_kernel<TM, TN, KB, NST, OCC, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)G2_K(false, false, false, false), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)G2_K(false, false, true, false), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)G2_K(true, false, false, false), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)G2_K(true, true, false, false), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)G2_K(true, false, false, true), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)G2_K(false, false, false, true), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   const dim3 grid(N / (64 * TN), mt_packed / (2 * TM)), block(256);
-#define G2_GO(A, P, R) hipLaunchKernelGGL((vit_gemm_lds_kernel<TM, TN, KB, NST, OCC, A, P, R>), grid, block, lds, s, xs, wp, bias, res, y, y_pre, M, N, K)
-  if (act && y_pre) G2_GO(true, true, false);
-  else if (act) G2_GO(true, false, false);
-  else if (res) G2_GO(false, false, true);
-  else G2_GO(false, false, false);
+#define G2_GO(A, P, R, Q) hipLaunchKernelGGL((G2_K(A, P, R, Q)), grid, block, lds, s, xs, wp, bias, res, y, y_pre, ys, M, N, K)
+  if (ys && act) G2_GO(true, false, false, true);
+  else if (ys) G2_GO(false, false, false, true);
+  else if (act && y_pre) G2_GO(true, true, false, false);
+  else if (act) G2_GO(true, false, false, false);
+  else if (res) G2_GO(false, false, true, false);
+  else G2_GO(false, false, false, false);
 #undef G2_GO
+#undef G2_K
 }
 // the caller (avc_vit.hip) has packed whole groups of 4 row tiles; false = shape not covered (N, K not multiples of the block)
-bool avc_vit_gemm_lds(const void* xs, const void* wp, const float* bias, const float* res, float* y, float* y_pre, int M, int N, int K,
-                      int act, int mt_packed, void* stream) {
-  if ((K % (16 * G2_KB)) || (mt_packed % (2 * G2_TM)) || (N % (64 * G2_TN)) || (act && res)) return false;
-  g2_launch<G2_TM, G2_TN, G2_KB, G2_STAGES, G2_OCC>((const b8*)xs, (const b8*)wp, bias, res, y, y_pre, M, N, K, act, mt_packed, (hipStream_t)stream);
+// ys != NULL: the output goes out as the packed bf16 operand of the next linear (no fp32 y, no residual, no y_pre)
+bool avc_vit_gemm_lds(const void* xs, const void* wp, const float* bias, const float* res, float* y, float* y_pre, void* ys, int M, int N,
+                      int K, int act, int mt_packed, void* stream) {
+  if ((K % (16 * G2_KB)) || (mt_packed % (2 * G2_TM)) || (N % (64 * G2_TN)) || (act && res) || (ys && (res || y_pre))) return false;
+  g2_launch<G2_TM, G2_TN, G2_KB, G2_STAGES, G2_OCC>((const b8*)xs, (const b8*)wp, bias, res, y, y_pre, (b8*)ys, M, N, K, act, mt_packed,
+                                                    (hipStream_t)stream);
   return true;
 }

@@ -33,6 +33,9 @@ _SIGS = {
     "avc_vit_linear": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "avc_vit_linear_bwd_gelu": (c_int, [P, P, P, P, c_int, c_int, c_int, P, P]),
     "avc_vit_workspace_bytes": (c_long, [c_int, c_int]),
+    "avc_vit_ln_pack": (c_int, [P, P, P, c_float, c_int, c_int, P, P]),
+    "avc_vit_linear_packed": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "avc_vit_attention_fwd_packed": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "avc_vit_attention_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "avc_vit_attention_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "avc_probe_mfma": (c_int, [P, P, P, P, P, P, P]),

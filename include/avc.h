@@ -143,8 +143,8 @@ int avc_mc_emit(const float* u, int nx, int ny, int nz, float iso, const int* vf
  * y[M,N] = act(x[M,K] W^T + bias) (+ residual); W pre-packed bf16 [N/32][K/16][64][8] (lane (n,h): W[32t+n][16s+8h+j]).
  * act 1 = QuickGELU (y_pre, if given, receives the pre-activation for the backward).  The backward dX = dY W is the same
  * call with the packed W^T (weights are frozen in AvatarCLIP: main.py:260).  Any M: up to 128 rows (the per-iteration calls) one
- * 8-wavefront split-K workgroup per (32 columns, 32 rows); beyond (batched scoring) a tiled GEMM, one 4-wavefront workgroup per
- * 128 x 128 output block (N % 128 == 0). */
+ * 8-wavefront split-K workgroup per (32 columns, 32 rows); beyond (batched scoring) an LDS-staged GEMM, one 4-wavefront workgroup
+ * per 128 x 128 output block (N % 128 == 0, K % 32 == 0; csrc/avc_vit_gemm.hip). */
 int avc_vit_linear(const float* x, const void* w_packed, const float* bias, const float* residual, float* y,
                    float* y_pre, int M, int N, int K, int act, void* workspace /* avc_vit_workspace_bytes(M, K) */,
                    void* stream);
@@ -154,6 +154,18 @@ int avc_vit_linear_bwd_gelu(const float* dy, const float* pre, const void* wt_pa
                             void* workspace, void* stream);
 /* bytes of the bf16 fragment copy of x that avc_vit_linear builds in `workspace` */
 long avc_vit_workspace_bytes(int M, int K);
+/* The batched scoring calls (no gradient; hundreds of images: ShapeGen/main.py:104-128, AvatarAnimate pose_generation.py:79-110) keep
+ * the activations between the kernels as packed bf16 operands ([row tile][k-step][lane (row, half)][8], avc_vit_workspace_bytes(M, K)
+ * bytes for an [M,K] activation) instead of fp32 rows + a packing pass per linear:
+ *   avc_vit_ln_pack               LayerNorm(x[M,768]; gamma, beta, eps) (clip/model.py LayerNorm, fp32 statistics) -> packed
+ *   avc_vit_linear_packed         y = act(xs W^T + b) (+ residual) from a packed operand; with ys_packed != NULL the result leaves
+ *                                 packed for the next linear (then y, residual must be NULL), else fp32 y[M,N]
+ *   avc_vit_attention_fwd_packed  attention with its output packed for the out-projection (rows = b * 50 + token)
+ * Shapes: more than 128 rows' worth is not required, but N % 128 == 0 and K % 32 == 0 are. */
+int avc_vit_ln_pack(const float* x, const float* gamma, const float* beta, float eps, int M, int K, void* xs_packed, void* stream);
+int avc_vit_linear_packed(const void* xs_packed, const void* w_packed, const float* bias, const float* residual, float* y,
+                          void* ys_packed, int M, int N, int K, int act, void* stream);
+int avc_vit_attention_fwd_packed(const float* qkv, void* out_packed, int B, int T, int width, int heads, void* stream);
 /* multi-head self-attention of ResidualAttentionBlock over T=50 tokens, head dim 64: qkv[B,T,3W] -> out[B,T,W] */
 int avc_vit_attention_fwd(const float* qkv, float* out, int B, int T, int width, int heads, void* stream);
 /* text tower (perceptor.encode_text, main.py:276-288; clip/model.py): self-attention over T <= 128 tokens, head dim 64, with

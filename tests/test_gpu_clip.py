@@ -68,6 +68,34 @@ def test_vit_linear_and_attention_kernels():
 
 
 @gpu
+@pytest.mark.parametrize("B", [3, 8, 37])
+def test_batched_scoring_pipeline_matches_the_autograd_path_and_the_oracle(B, monkeypatch):
+    """ClipVisionB32._encode_image_batched (no-grad calls with 3+ images: LayerNorm / attention / c_fc hand packed bf16 operands to the
+    linear behind them) against the per-iteration path (fp32 rows + a packing pass per linear): the same arithmetic with the same
+    rounding points; what differs is the fp32 LayerNorm (own kernel vs torch), whose last-bit differences flip bf16 roundings that
+    twelve layers then carry along: cosine >= 0.99999, |d| <= 5e-3 of the norm (measured 2.5e-3 .. 3.0e-3 -- about what either
+    pipeline differs from the fp32 oracle by); and against the fp32 CPU oracle with the tolerance of test_encode_image_matches_oracle.  B = 37: 1850 rows = 14.5 row-tile groups (ragged
+    last block); B = 3: the smallest batched call (150 rows)."""
+    from avatarclip_amd import clip_vit as V
+    dev = torch.device("cuda")
+    sd = C.random_state_dict(0)
+    model = V.ClipVisionB32(sd, dev)
+    img = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(B))
+    with torch.no_grad():
+        assert V.PACKED_PIPELINE
+        e_packed = model.encode_image(img.to(dev)).cpu()
+        assert len(model._packed) == 3                      # the packed pipeline ran
+        monkeypatch.setattr(V, "PACKED_PIPELINE", False)
+        e_rows = model.encode_image(img.to(dev)).cpu()
+        ref = C.encode_image(sd, img[: min(B, 4)])
+    cos = torch.cosine_similarity(e_packed, e_rows, dim=-1)
+    rel = ((e_packed - e_rows).norm(dim=-1) / e_rows.norm(dim=-1)).max().item()
+    print("packed vs row pipeline: min cosine", cos.min().item(), "max relative difference", rel)
+    assert cos.min() > 0.99999 and rel < 5e-3
+    assert torch.cosine_similarity(e_packed[: ref.shape[0]], ref, dim=-1).min() > 0.9995
+
+
+@gpu
 def test_encode_image_matches_oracle():
     from avatarclip_amd import clip_vit as V
     dev = torch.device("cuda")

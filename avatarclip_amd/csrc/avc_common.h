@@ -158,14 +158,27 @@ __device__ __forceinline__ void load8(const float* __restrict__ tab, int s, int 
 // canonicalisation (the bias add used to provide it for free); v_med3_f32(t, 0, 3e38) needs none.  (NOT inline asm: the hazard
 // recogniser does not look inside an asm, and a VALU read of an MFMA result without the wait states it inserts returns the
 // previous contents of the first result registers -- seen as 12 wrong columns in the last tile of a layer.)
+#ifndef AVC_SOFTPLUS_DIRECT
+#define AVC_SOFTPLUS_DIRECT 1
+#endif
 __device__ __forceinline__ float relu_raw(float t) { return __builtin_amdgcn_fmed3f(t, 0.f, 3.0e38f); }   // (a finite bound: +inf folds back to fmaxnum)
 __device__ __forceinline__ float softplus2(float t) {
   // H = S * Softplus_beta100(t / S)  (nn.Softplus(beta=100), fields.py:68) in base-2 units; raw v_exp_f32 / v_log_f32
 #ifdef AVC_ABL_CHEAPACT   // timing ablation only (what the transcendentals cost)
   return fmaxf(t, 0.f);
 #endif
+#if AVC_SOFTPLUS_DIRECT
+  // H = log2(1 + 2^t) as written -- v_exp, v_add, v_log -- plus ONE v_med3 that repairs the only range where that fails: 2^t
+  // overflows for t >= 128, the logarithm returns +inf, and the median of (+inf, t, 128) is t (= H to fp32 precision there); below,
+  // t <= L <= max(t, 0) + 1 <= 128 makes L the median.  2 plain + 2 transcendental instructions per element; the split form below
+  // (max(t, 0) + log2(1 + 2^-|t|)) needs 3 + 2, and plain VALU issue is what these kernels are short of.
+  // Very negative t: 2^t underflows to 0, L = 0 (true value 2^t log2 e < 2^-126).  Absolute error vs the split form <= 1 ulp of fp32.
+  const float L = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(t));
+  return __builtin_amdgcn_fmed3f(L, t, 128.f);
+#else
   const float e = __builtin_amdgcn_exp2f(-fabsf(t));
   return relu_raw(t) + __builtin_amdgcn_logf(1.f + e);
+#endif
 }
 // sigma(beta a) recovered from H = S * softplus(a):  1 - 2^-H
 __device__ __forceinline__ float sig_from_h(float H) { return 1.f - __builtin_amdgcn_exp2f(-H); }

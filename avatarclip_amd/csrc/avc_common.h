@@ -201,6 +201,42 @@ __device__ __forceinline__ void acc_to_frags(const float (&a)[16], V& f0, V& f1)
   pin2(f0, f1);
 }
 
+// ReLU of an accumulator tile straight into its two f16 fragments: convert first (v_cvt_pk_f16_f32), then take the maximum with 0
+// on the 16-bit patterns as SIGNED INTEGERS (v_pk_max_i16: a negative float, -0 included, is a negative integer; a positive one is
+// itself) -- 8 + 8 packed instructions per tile instead of 16 v_med3 + 8 conversions; the same values (the conversion is monotonic
+// and keeps the sign).  Returns the ReLU mask of the tile for the backward pass when WANT_BITS: bit p = element 2 p of the
+// accumulator registers is > 0, bit 8 + p = element 2 p + 1 (p = 0..7) -- i.e. register r sits at bit relu_mask_bit(r) -- gathered
+// with one v_pk_min_u16 (pattern -> 0 / 1 per half) and one v_lshl_or per register pair.  (A positive value below the smallest f16
+// subnormal, 6e-8, counts as 0 here: its activation IS 0 in the operand the next layer multiplies.)
+__host__ __device__ constexpr int relu_mask_bit(int r) { return (r >> 1) + 8 * (r & 1); }
+template <bool WANT_BITS, typename A>
+__device__ __forceinline__ unsigned relu_frags(const A& acc, h8& f0, h8& f1) {
+  typedef unsigned u4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { f0[j] = (_Float16)acc[j]; f1[j] = (_Float16)acc[8 + j]; }
+  pin2(f0, f1);                                    // (the conversions as v_cvt_pk_f16_f32 pairs, like acc_to_frags)
+  u4v w[2] = {__builtin_bit_cast(u4v, f0), __builtin_bit_cast(u4v, f1)};
+  unsigned m = 0u;
+  // (inline asm: hipcc rewrites the generic forms -- min(x, 1) becomes two 16-bit compares + selects, the packed maximum a
+  // compare + select per half.  Its operands are conversion results, not MFMA results: no hazard the assembler has to see.)
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    unsigned x = w[p >> 2][p & 3];
+    asm("v_pk_max_i16 %0, %1, 0" : "=v"(x) : "v"(x));
+    w[p >> 2][p & 3] = x;
+    if (WANT_BITS) {
+      unsigned q;
+      asm("v_pk_min_u16 %0, %1, %2" : "=v"(q) : "v"(x), "s"(0x00010001u));
+      if (p == 0) m = q;
+      else asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(m) : "v"(q), "n"(p), "v"(m));   // bit p: element 2 p, bit 16 + p: element 2 p + 1
+    }
+  }
+  f0 = __builtin_bit_cast(h8, w[0]);
+  f1 = __builtin_bit_cast(h8, w[1]);
+  pin2(f0, f1);
+  return WANT_BITS ? ((m & 0xffu) | (m >> 8)) : 0u;   // -> bits 0..7 | 8..15 (the callers store 16 bits)
+}
+
 __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32); }
 
 // Positional-encoding slots (host mirror: packing.pe_slot_table):

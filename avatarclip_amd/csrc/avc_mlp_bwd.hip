@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
         dof[0][r] = (__bf16)(dr * c * (1.f - c));
       }
       tile_store<false>(tiles, L::G_DO, dof[0], zero_frag<b8>());
-      // ReLU masks of r1 / r2 (16 bits per tile and lane, written by the forward kernel)
+      // ReLU masks of r1 / r2 (16 bits per tile and lane, written by the forward kernel: accumulator register r at bit relu_mask_bit(r))
       unsigned m1[N::HT], m2[N::HT];
 #pragma unroll
       for (int t = 0; t < N::HT; ++t) {
@@ -120,8 +120,8 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(PointSrc ps, long
 #define AVC_RELU_BWD(OUT, MSK, PT)                                                                         \
   AVC_EPI(const unsigned bits = MSK[t];                                                                      \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                    \
-            OUT[2 * t][j] = (__bf16)(((bits >> j) & 1u) ? acc[j] : 0.f);                                     \
-            OUT[2 * t + 1][j] = (__bf16)(((bits >> (8 + j)) & 1u) ? acc[8 + j] : 0.f); }                     \
+            OUT[2 * t][j] = (__bf16)(((bits >> relu_mask_bit(j)) & 1u) ? acc[j] : 0.f);                      \
+            OUT[2 * t + 1][j] = (__bf16)(((bits >> relu_mask_bit(8 + j)) & 1u) ? acc[8 + j] : 0.f); }        \
           pin2(OUT[2 * t], OUT[2 * t + 1]);                                                                  \
           tile_store<false>(tiles, (PT) + t, OUT[2 * t], OUT[2 * t + 1]);)
       b8 dl[N::HK];

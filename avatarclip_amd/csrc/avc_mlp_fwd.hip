@@ -276,15 +276,11 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
         feat[2 * t] = d.a0;
         feat[2 * t + 1] = d.a1;
       }
-      // ReLU layers; TRAIN: the activations go out as weight-gradient operands and their sign bits (16 per tile and lane) as the
+      // ReLU layers; TRAIN: the activations go out as weight-gradient operands and their > 0 bits (16 per tile and lane, relu_frags) as the
       // masks of the backward pass -- both from the hook of the next layer
 #define AVC_F_RELU(OUT, ML)                                                                   \
-  AVC_EPI(float a[16];                                                                        \
-          unsigned bits = 0u;                                                                 \
-          _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                    \
-            a[r] = relu_raw(acc[r]); if (TRAIN) bits |= (a[r] > 0.f ? 1u : 0u) << r; }        \
-          if constexpr (TRAIN && !ABL_NOMASK) mk[((ML) * N::HT + t) * 64] = (unsigned short)bits; \
-          acc_to_frags(a, OUT[2 * t], OUT[2 * t + 1]);)
+  AVC_EPI(const unsigned bits = relu_frags<TRAIN>(acc, OUT[2 * t], OUT[2 * t + 1]);            \
+          if constexpr (TRAIN && !ABL_NOMASK) mk[((ML) * N::HT + t) * 64] = (unsigned short)bits;)
 #if AVC_SPREAD_STORES
 #define AVC_F_RSTORE(PT, R)                                                                   \
   AVC_HOOKG(if constexpr (TRAIN && !ABL_NORSTORE) tiles_store_part<false, N::HT>(tiles, PT, R, grp_, ngrp_);)

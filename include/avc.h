@@ -78,7 +78,8 @@ int avc_composite_bwd(const float* sdf, const float* normal, const float* rgb, c
  * written to the F REGION of the OPERAND PANELS: per 32-point block avc_fwd_panel_tiles(net) tiles of 2 KiB, each tile = the
  * two 16-bit B-operand fragments [k-step][lane = point + 32 half][8 features] of 32 features x 32 points (f16: PE values,
  * h_l, g_a,l, feature vector, [x,n], r1, r2), and the ReLU masks of r1 / r2 (avc_mask_u16_per_block(net) x 16 bits per
- * block).  Both buffers need (nblk + 1) blocks, nblk = ceil(npts / 32): the last block is a sink for wavefronts past the end.
+ * block: [layer][tile][lane], bit (r >> 1) + 8 (r & 1) = feature row r of the lane's 16 rows is > 0 -- opaque to the caller, the
+ * backward kernel is the only reader).  Both buffers need (nblk + 1) blocks, nblk = ceil(npts / 32): the last block is a sink for wavefronts past the end.
  * The gradient-type operands (bf16: gbar_h, abar, delta, ybar) live in a separate G REGION of avc_grad_panel_tiles(net) tiles
  * per block that only ever holds one SLAB of blocks (see avc_render_points_bwd). */
 int avc_fwd_panel_tiles(int net);

@@ -212,3 +212,34 @@ def test_panel_plan_arithmetic():
     # tiny ray sets are never cut
     assert plan_panels(1, 64, 1 << 26, blk_f, blk_g, 256 * 1024, 32 * 1024) == (1, 1)
     assert plan_panels(33, 64, 1 << 26, blk_f, blk_g, 256 * 1024, 32 * 1024) == (33, 33)
+
+
+def test_softplus_direct_form_and_relu_mask_bit_order_restated():
+    """The two instruction-level rewrites of round 3, restated in numpy / plain Python (the GPU parity tests exercise the kernels; this
+    pins the arithmetic they rely on without a GPU):
+      * csrc/avc_common.h softplus2: H = median(log2(1 + 2^t), t, 128) in fp32 equals the split form max(t, 0) + log2(1 + 2^-|t|)
+        over the whole range, including t >= 128 where 2^t overflows and the logarithm returns +inf;
+      * csrc/avc_common.h relu_frags / relu_mask_bit: gathering bit p from the LOW half and bit 16 + p from the HIGH half of register
+        pair p (v_pk_min_u16 + v_lshl_or), folded to 16 bits as (m & 0xff) | (m >> 8), puts accumulator register r at bit
+        (r >> 1) + 8 (r & 1) -- the position the backward kernel tests."""
+    t = np.concatenate([np.linspace(-200, 200, 4001), np.array([-1e4, -127.9, 126.5, 127.999, 128.0, 128.5, 300.0, 6e4])]).astype(np.float32)
+    with np.errstate(over="ignore"):
+        L = np.log2(np.float32(1) + np.exp2(t)).astype(np.float32)           # +inf where 2^t overflows
+    direct = np.median(np.stack([L, t, np.full_like(t, 128.0)]), axis=0).astype(np.float32)
+    split = (np.maximum(t, 0) + np.log2(np.float32(1) + np.exp2(-np.abs(t)))).astype(np.float32)
+    assert np.isfinite(direct).all()
+    assert np.abs(direct - split).max() <= 2e-6 * max(1.0, 0) + np.abs(split).max() * 2.4e-7     # one fp32 ulp of the larger values
+    assert (direct[t >= 128] == t[t >= 128]).all()
+    # mask bit order: registers a[0..15] of one lane -> 8 register pairs (a[2p], a[2p+1]) after the f16 conversion
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        a = rng.standard_normal(16).astype(np.float32)
+        a[rng.integers(0, 16, 4)] = 0.0
+        m = 0
+        for p in range(8):
+            lo, hi = a[2 * p] > 0, a[2 * p + 1] > 0           # v_pk_max_i16 + v_pk_min_u16: 1 per half whose relu'd f16 pattern is non-zero
+            m |= (int(lo) | (int(hi) << 16)) << p
+        bits = (m & 0xFF) | (m >> 8)
+        for r in range(16):
+            assert ((bits >> ((r >> 1) + 8 * (r & 1))) & 1) == int(a[r] > 0), (r, a)
+        assert bits < (1 << 16)

@@ -174,8 +174,9 @@ class Engine:
     _by_net = weakref.WeakKeyDictionary()
     PROFILE = False               # bench.py: record (name, points, start_event, end_event) per kernel launch group
     prof_events = []
-    WG_BLOCKS_PER_SPLIT = int(os.environ.get("AVC_WG_BLOCKS_PER_SPLIT", "1024"))    # split-K of the weight-gradient launch: blocks per workgroup (nsplit = blocks / this, 1..256; one slab of
-                                  # 131072 blocks = 128 splits x 13 pairs = 1664 workgroups over 256 CUs)
+    WG_BLOCKS_PER_SPLIT = int(os.environ.get("AVC_WG_BLOCKS_PER_SPLIT", "256"))     # split-K of the weight-gradient launch: blocks per workgroup (nsplit = blocks / this, 1..256).  A
+                                  # 512^2 x 64 spp slab (262144 blocks) has its 256 splits either way; smaller point sets want the finer deal -- at 224^2 (100352
+                                  # blocks) 256 splits x 17 pairs instead of 98 x 17 workgroups over 256 CUs: 8.52 -> 8.08 ms (profiles/r03_ab_kernels.txt)
     MAX_FWD_WAVES = 2048          # persistent grid of avc_render_points_fwd: 256 CUs x one 8-wave workgroup
     MAX_BWD_WAVES = 2048          # 256 CUs x one 8-wave workgroup
     # Operand panels (csrc/avc_mlp.h: PanelLayout).  F region: 89 tiles = 5.6 KiB per point (full nets), written by the training

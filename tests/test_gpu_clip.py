@@ -96,6 +96,30 @@ def test_batched_scoring_pipeline_matches_the_autograd_path_and_the_oracle(B, mo
 
 
 @gpu
+@pytest.mark.parametrize("B", [1, 2])
+def test_training_call_replayed_as_hip_graphs_is_bit_identical_to_eager_launches(B, monkeypatch):
+    """ClipVisionB32.encode_image with a gradient to the pixels (the per-iteration call, main.py:512,524): forward and backward replayed
+    as HIP graphs must give exactly what the eager launches give -- embeddings and pixel gradients bit for bit, on fresh inputs and
+    on repeated replays."""
+    from avatarclip_amd import clip_vit as V
+    dev = torch.device("cuda")
+    model = V.ClipVisionB32(C.random_state_dict(0), dev)
+    text = torch.randn(1, 512, generator=torch.Generator().manual_seed(5)).to(dev)
+    assert V.TRAIN_GRAPH
+    for k in range(3):
+        img = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(10 + k)).to(dev)
+        out = []
+        for graph in (True, False):
+            monkeypatch.setattr(V, "TRAIN_GRAPH", graph)
+            x = img.clone().requires_grad_(True)
+            e = model.encode_image(x)
+            (1 - torch.cosine_similarity(e.mean(0), text.mean(0), dim=0)).backward()
+            out.append((e.detach().clone(), x.grad.clone()))
+        assert B in model._graphed                              # the graphed route ran
+        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]), k
+
+
+@gpu
 def test_encode_image_matches_oracle():
     from avatarclip_amd import clip_vit as V
     dev = torch.device("cuda")

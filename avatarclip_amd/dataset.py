@@ -109,10 +109,11 @@ class SMPL_Dataset:
         device and the only host round trip left is the scalar that fixes the ray-grid size (a dynamic shape)."""
         m0 = torch.as_tensor(mask, device=self.device)
         m0 = (m0 != 0).float()
-        if float(m0.sum()) == 0:
-            return self.gen_rays_pose(pose, resolution_level=4)
         dilated = torch.nn.functional.max_pool2d(m0[None, None], kernel_size=21, stride=1, padding=10)[0, 0]
-        ratio = float(dilated.sum()) / float(m0.shape[0] * m0.shape[1])
+        n_mask, n_dilated = torch.stack([m0.sum(), dilated.sum()]).tolist()      # ONE round trip for both counts
+        if n_mask == 0:
+            return self.gen_rays_pose(pose, resolution_level=4)
+        ratio = float(n_dilated) / float(m0.shape[0] * m0.shape[1])
         Wn = Hn = min(self.H, int(np.sqrt(max_ray_num / ratio)))
         dev = self.device
         tx = torch.linspace(0, self.W - 1, Wn, device=dev)
@@ -121,7 +122,10 @@ class SMPL_Dataset:
         o, v = self._dirs(px.t(), py.t(), torch.as_tensor(pose))
         m = torch.nn.functional.interpolate(dilated.reshape(1, 1, *dilated.shape), size=(Hn, Wn)).squeeze()
         sel = m > 0
-        return o[sel], v[sel], Wn, sel
+        # the row-major positions of the selected pixels: the second (and last) round trip -- it fixes the ray count.  Everything
+        # downstream gathers / scatters with these indices (same order as boolean-mask indexing) without another synchronisation.
+        self.last_sel_idx = sel.reshape(-1).nonzero().squeeze(1)
+        return o.reshape(-1, 3).index_select(0, self.last_sel_idx), v.reshape(-1, 3).index_select(0, self.last_sel_idx), Wn, sel
 
     def near_far_from_sphere(self, rays_o, rays_d, is_sphere=False):
         """dataset.py:331-342 (`is_sphere` is ignored by the reference too)."""

@@ -384,9 +384,11 @@ class Runner:
         prior = self.prior_renderer(eye, at)
         true_rgb = torch.as_tensor(prior, dtype=torch.float32, device=dev)
         ori_mask = (true_rgb != 0).float()[..., 0]
-        dilated_mask = None
+        dilated_mask = sel_idx = None
         if self.use_silhouettes:
+            self.dataset.last_sel_idx = None
             rays_o, rays_d, W, dilated_mask = self.dataset.gen_rays_silhouettes(pose, self.max_ray_num, ori_mask)
+            sel_idx = getattr(self.dataset, "last_sel_idx", None)
             H = W
             rays_o, rays_d = rays_o.float(), rays_d.float()
         else:
@@ -400,7 +402,34 @@ class Runner:
         near, far = self.dataset.near_far_from_sphere(rays_o, rays_d)
         return types.SimpleNamespace(eye=eye, at=at, theta=theta, phi=phi, is_front=is_front, pose=pose, H=H, W=W,
                                      rays_o=rays_o, rays_d=rays_d, near=near, far=far, true_rgb=true_rgb, mask=mask,
-                                     dilated_mask=dilated_mask)
+                                     dilated_mask=dilated_mask, sel_idx=sel_idx)
+
+    def make_view_on_side_stream(self, iter_i, camera=None):
+        """make_view for the silhouette mode, enqueued on a second HIP stream.  The ray set of that mode has a data-dependent size, so
+        make_view has to bring two numbers to the host (dataset.gen_rays_silhouettes); on the main stream each of those round trips
+        waits for EVERYTHING enqueued before it -- the previous iteration's backward pass -- and the host, which would otherwise run
+        an iteration ahead of the GPU, falls into lock-step with it.  The view depends on nothing the optimiser writes: on its own
+        stream its round trips wait for its own few small kernels only.  Host order -- and with it every numpy / torch random draw --
+        is unchanged; the main stream waits for the view's event before its first use, and every tensor of the view is registered
+        with the main stream so the caching allocator does not hand its memory back to the side stream while main-stream kernels
+        still read it.  (In full-frame mode there is nothing to gain: no round trips, and small kernels do not become resident beside
+        the persistent MLP kernels -- profiles/r03_side_stream.txt.)  AVC_OVERLAP_HEAD=0: everything on one stream."""
+        if self.device.type != "cuda" or os.environ.get("AVC_OVERLAP_HEAD", "1") == "0":
+            return self.make_view(iter_i, camera)
+        main = torch.cuda.current_stream(self.device)
+        side = getattr(self, "_side_stream", None)
+        if side is None:
+            side = self._side_stream = torch.cuda.Stream(device=self.device)
+            side.wait_stream(main)       # first use: whatever initialisation is still in flight on the main stream
+        with torch.cuda.stream(side):
+            view = self.make_view(iter_i, camera)
+            ready = torch.cuda.Event()
+            ready.record(side)
+        main.wait_event(ready)
+        for t in vars(view).values():
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(main)
+        return view
 
     def draw_background(self, view, choice_i=None):
         """main.py:387-415 -> (choice_i, background_rgb [1,3] | [H*W,1] | None, what render() gets)."""
@@ -418,7 +447,9 @@ class Runner:
             sigma = torch.empty(1).uniform_(0.1, 2.0).item()   # torchvision GaussianBlur.get_params: torch CPU RNG
             background_rgb = chess_background(H, W, chess_length, sigma, dev)
         if self.use_silhouettes and choice_i in (1, 2):
-            masked_background_rgb = background_rgb.reshape(H, W, 1)[view.dilated_mask].reshape(-1, 1)
+            idx = getattr(view, "sel_idx", None)      # (gather by index: boolean-mask indexing would synchronise the stream for the count)
+            masked_background_rgb = background_rgb.reshape(-1, 1).index_select(0, idx) if idx is not None else \
+                background_rgb.reshape(H, W, 1)[view.dilated_mask].reshape(-1, 1)
         else:
             masked_background_rgb = background_rgb
         return choice_i, background_rgb, masked_background_rgb
@@ -458,10 +489,13 @@ class Runner:
             background = torch.zeros([H, W, 3], device=dev)
             if choice_i == 0:
                 background[:] = 1
-            if choice_i in (1, 2):
-                background[~dilated_mask] = background_rgb.reshape(H, W, 1).repeat(1, 1, 3)[~dilated_mask]
+            if choice_i in (1, 2):   # (= background[~dilated_mask] = bg[~dilated_mask], without the count a boolean index needs)
+                background = torch.where(dilated_mask[..., None], background, background_rgb.reshape(H, W, 1).expand(H, W, 3))
+            idx = getattr(view, "sel_idx", None)
 
             def scatter(vals, base):
+                if idx is not None:      # row-major positions of the mask's pixels (dataset.gen_rays_silhouettes): no synchronisation
+                    return base.reshape(-1, vals.shape[-1]).index_copy(0, idx, vals)
                 full = base.clone()
                 full[dilated_mask] = vals
                 return full.reshape(-1, vals.shape[-1])
@@ -513,7 +547,7 @@ class Runner:
 
     def clip_loss(self, iter_i, camera=None):
         """main.py:348-534: one view from camera to scalar loss (differentiable)."""
-        view = self.make_view(iter_i, camera)
+        view = self.make_view_on_side_stream(iter_i, camera) if self.use_silhouettes else self.make_view(iter_i, camera)
         choice_i, background_rgb, masked_background_rgb = self.draw_background(view)
         render_out = self.renderer.render(view.rays_o, view.rays_d, view.near, view.far, background_rgb=masked_background_rgb,
                                           cos_anneal_ratio=self.get_cos_anneal_ratio())

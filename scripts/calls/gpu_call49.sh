@@ -1,0 +1,8 @@
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R && mkdir -p gpurun_out
+timeout 120 python - <<'PY' || { echo "HEALTH CHECK FAILED (box, not repo code)"; exit 0; }
+import torch
+x = torch.randn(4096, 4096, device="cuda"); y = (x @ x).sum().item(); print("torch matmul ok", y == y)
+PY
+timeout 900 python -m pytest tests/test_gpu_iteration.py tests/test_gpu_dataset_train.py -m gpu -q --timeout 900 2>&1 | tail -3
+( timeout 300 python scripts/silhouette_time.py 7000 512 40; AVC_OVERLAP_HEAD=0 timeout 300 python scripts/silhouette_time.py 7000 512 40; timeout 300 python scripts/silhouette_time.py 7000 512 40 ) 2>&1 | grep "silhouette mode" | tee gpurun_out/c49_silhouette.txt

@@ -114,6 +114,12 @@ def test_runner_glue_matches_reference_lines(case):
     for name in ("color_fine", "extra_color_fine", "weight_sum", "texture_shading", "rand_shading_rgb"):
         if name in d:
             assert np.abs(comp[name].numpy() - d[name]).max() < 1e-6, name
+    if sil:   # the product's own views carry the row-major pixel positions of the mask (dataset.gen_rays_silhouettes) and scatter /
+              # gather by index instead of by boolean mask (no stream synchronisation): the same images
+        view.sel_idx = view.dilated_mask.reshape(-1).nonzero().squeeze(1)
+        comp_i = r.shade_and_scatter(out, view, choice, bg_rgb, light=(d["light_dir"], float(d["ambience"])))
+        for name, v in comp.items():
+            assert (v is None and comp_i[name] is None) or torch.equal(v, comp_i[name]), name
     loss, parts = r.assemble_loss(out, comp, view, iter_i)
     for name, val in (("color_fine_loss", parts["color"]), ("eikonal_loss", parts["eikonal"]), ("mask_loss", parts["mask"]),
                       ("cosine", parts["cosine"]), ("loss", loss)):

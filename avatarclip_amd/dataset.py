@@ -17,6 +17,8 @@ class SMPL_Dataset:
         self.conf = conf
         self.images = None
         self.masks = None
+        self._images_dev = None
+        self._pin, self._pin_i = [(None, None)] * 4, 0
         self.poses = None
         self.images_lis = []
         data_dir = None if conf is None else conf.get_string("data_dir", default=None)
@@ -94,13 +96,45 @@ class SMPL_Dataset:
         return self.gen_rays_pose(torch.from_numpy(pose), resolution_level)
 
     def gen_random_rays_at(self, img_idx, batch_size):
-        """dataset.py:314-329 -> [B,10] = o, d, rgb, mask."""
+        """dataset.py:314-329 -> [B,10] = o, d, rgb, mask.  The pixel draws are the reference's (torch's CPU generator, x then y); the
+        look-ups run on the device from a device copy of the images: the reference's CPU fancy-indexing + pageable uploads cost
+        34 ms per 5 120-ray batch on a 256-core host (a parallel CPU gather per call, then blocking copies ordered behind the whole
+        previous iteration) against 3 ms of GPU work -- profiles/r03_silhouette_mode.txt."""
         px = torch.randint(low=0, high=self.W, size=[batch_size])
         py = torch.randint(low=0, high=self.H, size=[batch_size])
-        color = self.images[img_idx][(py, px)]
-        mask = self.masks[img_idx][(py, px)]
-        o, v = self._dirs(px.to(self.device).float(), py.to(self.device).float(), self.poses[img_idx])
-        return torch.cat([o, v, color.to(self.device), mask[:, :1].to(self.device)], dim=-1)
+        if self.device.type != "cuda":
+            color = self.images[img_idx][(py, px)]
+            mask = self.masks[img_idx][(py, px)]
+            o, v = self._dirs(px.float(), py.float(), self.poses[img_idx])
+            return torch.cat([o, v, color, mask[:, :1]], dim=-1)
+        if self._images_dev is None:
+            self._images_dev = self.images.to(self.device)
+        pxy = self._upload_pixels(px, py)                                       # [2,B] int64 on the device, without blocking the host
+        flat = pxy[1] * self.W + pxy[0]
+        color = self._images_dev[int(img_idx)].reshape(-1, 3).index_select(0, flat)
+        mask = (color[:, :1] != 0).to(color.dtype)                              # dataset.py:228-229: masks[images != 0] = 1, channel 0
+        o, v = self._dirs(pxy[0].float(), pxy[1].float(), self.poses[int(img_idx)])
+        return torch.cat([o, v, color, mask], dim=-1)
+
+    def _upload_pixels(self, px, py):
+        """pixel indices -> device through a small ring of pinned staging buffers (a slot is reused only after the event recorded
+        behind its copy has completed): a `.to(device)` from pageable memory would block the host behind the previous iteration"""
+        n = px.numel()
+        slot = self._pin_i % 4
+        self._pin_i += 1
+        buf, ev = self._pin[slot]
+        if buf is None or buf.shape[1] < n:
+            buf = torch.empty(2, max(n, 1024), dtype=torch.int64).pin_memory()
+        elif ev is not None:
+            ev.synchronize()
+        buf[0, :n].copy_(px)
+        buf[1, :n].copy_(py)
+        with torch.cuda.device(self.device):
+            out = buf[:, :n].to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+        self._pin[slot] = (buf, ev)
+        return out
 
     def gen_rays_silhouettes(self, pose, max_ray_num, mask):
         """dataset.py:252-275: rays only inside the 10x-dilated silhouette `mask` [256,256].

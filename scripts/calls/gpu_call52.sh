@@ -1,0 +1,8 @@
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R && mkdir -p gpurun_out
+timeout 120 python - <<'PY' || { echo "HEALTH CHECK FAILED (box, not repo code)"; exit 0; }
+import torch
+x = torch.randn(4096, 4096, device="cuda"); y = (x @ x).sum().item(); print("torch matmul ok", y == y)
+PY
+timeout 900 python -m pytest tests/test_gpu_dataset_train.py tests/test_gpu_iteration.py -m gpu -q --timeout 900 -k "dataset or neus_init or standpose or shapegen or train" 2>&1 | tail -3
+( timeout 300 python scripts/train_time.py 512 200; timeout 300 python scripts/train_time.py 5120 100 ) 2>&1 | grep "Runner.train" | tee gpurun_out/c52_train_time.txt

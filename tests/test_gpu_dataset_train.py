@@ -46,6 +46,15 @@ def test_train_on_the_reference_standpose_dataset(tmp_path):
     dev = torch.device("cuda")
     r = Runner(None, mode="train", conf=conf, device=dev)
     assert r.dataset.n_images == 108 and r.dataset.H == 256 and abs(r.dataset.focal - 0.5 * 256 / np.tan(np.pi / 6)) < 1e-3
+    # ---- the device-side batch look-up (device copy of the images, pinned index upload) = the reference's CPU look-up on the same draws
+    from avatarclip_amd.dataset import SMPL_Dataset
+    ds_cpu = SMPL_Dataset(conf["dataset"], device=torch.device("cpu"))
+    for bs in (512, 5120):
+        torch.manual_seed(11)
+        a = r.dataset.gen_random_rays_at(torch.tensor(7), bs).cpu()
+        torch.manual_seed(11)
+        b = ds_cpu.gen_random_rays_at(torch.tensor(7), bs)
+        assert torch.equal(a[:, 6:], b[:, 6:]) and (a[:, :6] - b[:, :6]).abs().max() < 1e-5
     # ---- first iteration vs the oracle on the same batch
     torch.manual_seed(3)
     data = r.dataset.gen_random_rays_at(58, 1024)

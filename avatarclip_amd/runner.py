@@ -440,7 +440,9 @@ class Runner:
         if choice_i == 0:
             background_rgb = torch.ones([1, 3], device=dev)
         elif choice_i == 1:
-            gaussian = torch.normal(torch.zeros([H, W, 1], device=dev) + 0.5, torch.zeros([H, W, 1], device=dev) + 0.2)
+            # (= torch.normal(zeros + 0.5, zeros + 0.2), main.py:393-394, draw for draw -- without the host-side check of the std TENSOR
+            # that form makes, a stream synchronisation; test_gpu_iteration compares the two on the device)
+            gaussian = torch.randn([H, W, 1], device=dev) * 0.2 + 0.5
             background_rgb = torch.clamp(gaussian, min=0, max=1).reshape(-1, 1)
         elif choice_i == 2:
             chess_length = H // np.random.choice(np.arange(10, 20))
@@ -822,8 +824,8 @@ def chess_background(H, W, chess_length, sigma, device):
 
 def _gaussian_blur(x, ksize, sigma):
     """separable gaussian blur of [1,C,H,W] with reflect padding (torchvision.transforms.GaussianBlur semantics)."""
-    def k1d(k):
-        r = torch.arange(k, device=x.device, dtype=x.dtype) - (k - 1) / 2
+    def k1d(k):      # (on the host: the taps are nine numbers, and a .tolist() of a device tensor would synchronise the stream)
+        r = torch.arange(k, dtype=x.dtype) - (k - 1) / 2
         w = torch.exp(-0.5 * (r / sigma) ** 2)
         return w / w.sum()
     kx, ky = k1d(ksize[0]).tolist(), k1d(ksize[1]).tolist()

@@ -255,6 +255,18 @@ def test_runner_train_neus_init_and_checkpoint_round_trip(tmp_path, extra_color)
 
 
 @gpu
+def test_gaussian_background_draw_equals_torch_normal_of_tensors_on_the_device():
+    """draw_background's choice 1 (main.py:393-394: torch.normal(zeros + 0.5, zeros + 0.2)) is written as randn * 0.2 + 0.5 -- the same
+    draws without the host-side validation of the std tensor (a stream synchronisation per iteration)"""
+    dev = torch.device("cuda")
+    torch.manual_seed(7)
+    a = torch.normal(torch.zeros([96, 96, 1], device=dev) + 0.5, torch.zeros([96, 96, 1], device=dev) + 0.2)
+    torch.manual_seed(7)
+    b = torch.randn([96, 96, 1], device=dev) * 0.2 + 0.5
+    assert torch.equal(a, b)
+
+
+@gpu
 def test_train_clip_iteration_with_silhouette_rays_and_background_augmentation():
     """the reference's default sampling mode (use_silhouettes = True, main.py:360-375): a ragged, per-iteration ray set inside the
     dilated SMPL silhouette, scattered back into the image for CLIP, with every background augmentation (main.py:387-415)"""

@@ -243,8 +243,15 @@ class ClipVisionB32:
             g = self._graphed.get(B)
             if g is None:
                 sample = torch.zeros(B, 3, RES, RES, device=self.device, dtype=torch.float32, requires_grad=True)
-                g = self._graphed[B] = torch.cuda.make_graphed_callables(self._encode_image_eager, (sample,))
-            return g(image.float())
+                try:
+                    g = torch.cuda.make_graphed_callables(self._encode_image_eager, (sample,))
+                except Exception as e:      # a capture that the runtime refuses must not take the training run down: eager launches
+                    import logging
+                    logging.warning("CLIP encode_image: HIP graph capture failed (%s: %s); launching eagerly", type(e).__name__, str(e)[:200])
+                    g = False
+                self._graphed[B] = g
+            if g is not False:
+                return g(image.float())
         return self._encode_image_eager(image)
 
     def _encode_image_eager(self, image: torch.Tensor) -> torch.Tensor:

@@ -244,7 +244,8 @@ class ClipVisionB32:
             if g is None:
                 sample = torch.zeros(B, 3, RES, RES, device=self.device, dtype=torch.float32, requires_grad=True)
                 try:
-                    g = torch.cuda.make_graphed_callables(self._encode_image_eager, (sample,))
+                    with torch.cuda.device(self.device):     # (capture streams are created on the CURRENT device)
+                        g = torch.cuda.make_graphed_callables(self._encode_image_eager, (sample,))
                 except Exception as e:      # a capture that the runtime refuses must not take the training run down: eager launches
                     import logging
                     logging.warning("CLIP encode_image: HIP graph capture failed (%s: %s); launching eagerly", type(e).__name__, str(e)[:200])

@@ -2,6 +2,8 @@
 smplx.lbs helpers it calls: batch_rodrigues :72-106, vertices2joints, batch_rigid_transform), as plain torch on whatever device
 the arrays live on.  The licensed SMPL arrays (v_template, posedirs, J_regressor, parents, lbs_weights, faces) are INPUTS:
 `load_smpl_arrays` reads them from an .npz export or from the official pickle."""
+import os
+
 import numpy as np
 import torch
 
@@ -59,9 +61,18 @@ def load_smpl_arrays(path, device="cpu"):
     """.npz with the SMPL field names, or the official SMPL_*.pkl (chumpy objects are read through their `.r` array when the
     chumpy package is importable; posedirs is reshaped to [(J-1)*9, V*3] like smplx does)."""
     if path.endswith(".npz"):
-        d = dict(np.load(path, allow_pickle=True))
+        try:
+            d = dict(np.load(path, allow_pickle=False))      # plain arrays: nothing from the file is executed
+        except ValueError:
+            if os.environ.get("AVC_ALLOW_UNSAFE_PICKLE") != "1":
+                raise RuntimeError("%s holds pickled objects; loading it would execute code from the file (set AVC_ALLOW_UNSAFE_PICKLE=1 "
+                                   "to allow that, or re-save the arrays with np.savez)" % path)
+            d = dict(np.load(path, allow_pickle=True))
     else:
+        # the official SMPL_*.pkl IS a pickle (of chumpy objects): reading it executes code from the file, as smplx / the reference do
+        import logging
         import pickle
+        logging.warning("%s is a pickle: loading it executes code from the file (convert it to .npz to avoid that)", path)
         with open(path, "rb") as f:
             d = pickle.load(f, encoding="latin1")
     g = lambda k: np.asarray(d[k].r if hasattr(d[k], "r") else (d[k].todense() if hasattr(d[k], "todense") else d[k]))

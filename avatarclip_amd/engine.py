@@ -188,6 +188,13 @@ class Engine:
     # (BASELINE config 3 per GPU) = 174 GiB + 23-GiB slabs, still ONE chunk on a 288-GB MI355X.  Only when even that does not fit
     # the budget -- min(AVC_PANEL_GIB, 80 % of the free HBM) -- the ray set is cut into chunks and the backward re-runs the
     # training forward chunk by chunk.
+    # Role-specialised backward (csrc/avc_bwd_ring.hip): the abar tiles of the middle SDF layers are handed from the backward sweeps
+    # to accumulator-owning consumer workgroups of the same XCD through an L2-resident ring instead of through the G region.
+    # RING_CPT = consumer workgroups per (XCD, product), RING_SLOTS = ring slots (128 KiB each for the full nets) per (XCD, product).
+    RING = os.environ.get("AVC_BWD_RING", "0") != "0"
+    RING_CPT = int(os.environ.get("AVC_RING_CPT", "2"))
+    RING_SLOTS = int(os.environ.get("AVC_RING_SLOTS", "6"))
+    RING_CHECK = os.environ.get("AVC_RING_CHECK", "0") != "0"      # synchronise after every ring launch and raise on its error word
     PANEL_BYTES_BUDGET = int(os.environ.get("AVC_PANEL_GIB", "224")) << 30
     SLAB_BLOCKS = int(os.environ.get("AVC_SLAB_BLOCKS", str(256 * 1024)))
     MIN_SLAB_BLOCKS = 32 * 1024
@@ -218,6 +225,8 @@ class Engine:
         self._packed_key = None
         self._packed = None
         self._panel_owner = None      # token of the RenderCoreFn.forward whose operand panels the buffers hold
+        self._ring = None             # buffers of the role-specialised backward (lazily)
+        self.ring_stats = None        # RING_CHECK: the u64 counters of the last ring launch (include/avc.h)
 
     @classmethod
     def for_networks(cls, sdf_net, col_net):
@@ -269,6 +278,37 @@ class Engine:
 
     def _bufs_g(self, nblk_slab):
         return self._grow("_gpanels", (nblk_slab + 1) * self.grad_tiles * 2048)
+
+    def _ring_setup(self):
+        """buffers + pair tables of the role-specialised backward: (ctl, payload, partial, bias_partial, pb_tiles, pairs of the
+        remaining weight-gradient launch, [(out_off, bias_off)] of the ring products)"""
+        key = (self.RING_CPT, self.RING_SLOTS)
+        if self._ring is not None and self._ring["key"] == key:
+            return self._ring
+        lay, lib = self.dl.lay, self.lib
+        ht = self.spec.H // 32
+        ntypes = lib.avc_bwd_ring_types(self.net)
+        assert ntypes == self.spec.NMID
+        ring_rows, pb, offs = [], [], []
+        for m in range(ntypes):
+            row = [i for i, pr in enumerate(lay.pairs) if pr[0] == lay.panel["ABM"] + m * ht and pr[6] == 1]
+            assert len(row) == 1
+            pr = lay.pairs[row[0]]
+            assert pr[1] == ht and pr[3] == ht and pr[7] == 0 and pr[5] >= 0, "ring products are HT x HT with an F-region B operand and a bias"
+            ring_rows.append(row[0]); pb.append(int(pr[2])); offs.append((int(pr[4]), int(pr[5])))
+        rest = np.ascontiguousarray(np.delete(self._pairs_host, ring_rows, axis=0))
+        nrow = 8 * self.RING_CPT
+        dev = self.device
+        self._ring = dict(
+            key=key, ntypes=ntypes, ht=ht, offs=offs, rest=rest,
+            ctl=torch.zeros(lib.avc_bwd_ring_ctl_bytes() // 4, dtype=torch.int32, device=dev),
+            payload=torch.empty(lib.avc_bwd_ring_payload_bytes(self.net, ntypes, self.RING_SLOTS), dtype=torch.uint8, device=dev),
+            partial=torch.zeros(ntypes, nrow, ht * ht * 1024, dtype=torch.float32, device=dev),
+            bias=torch.zeros(ntypes, nrow, ht * 32, dtype=torch.float32, device=dev),
+            pb=(ctypes.c_int * ntypes)(*pb),
+            err=torch.zeros((), dtype=torch.int32, device=dev),
+            grid=torch.cuda.get_device_properties(dev).multi_processor_count)
+        return self._ring
 
     def _held_bytes(self):
         return sum(b.numel() * b.element_size() for b in (self._fpanels, self._gpanels, self._masks) if b is not None)
@@ -407,6 +447,10 @@ class Engine:
         st = L.stream()
         esz = 4
         scratch_out = None
+        rg = self._ring_setup() if self.RING else None
+        if rg is not None:
+            rg["err"].zero_()
+        pairs_host = rg["rest"] if rg is not None else self._pairs_host
         for c0 in range(0, R, rays_per_chunk):
             c1 = min(R, c0 + rays_per_chunk)
             if not panels_valid:
@@ -424,21 +468,40 @@ class Engine:
                 fptr = fpanels.data_ptr() + fblk0 * self.fwd_tiles * 2048
                 mptr = masks.data_ptr() + fblk0 * self.mask_u16 * 2
                 gpanels = self._bufs_g(nblk)
-                with Engine._Timed("avc_render_points_bwd", npts):
-                    L.check(self.lib.avc_render_points_bwd(
-                        self.net, None, rays_o.data_ptr() + s0 * 3 * esz, rays_d.data_ptr() + s0 * 3 * esz,
-                        z.data_ptr() + s0 * z.stride(0) * esz, S, z.stride(0), float(sample_dist), npts, L.ptr(pk.w_bf16), L.ptr(pk.tab),
-                        self.dl.offsets, d_sdf.data_ptr() + s0 * S * esz, d_n.data_ptr() + s0 * S * 3 * esz,
-                        d_rgb.data_ptr() + s0 * S * 6 * esz, rgb.data_ptr() + s0 * S * 6 * esz, fptr, L.ptr(gpanels), mptr,
-                        self.MAX_BWD_WAVES, st), "avc_render_points_bwd")
+                bwd_args = (self.net, None, rays_o.data_ptr() + s0 * 3 * esz, rays_d.data_ptr() + s0 * 3 * esz,
+                            z.data_ptr() + s0 * z.stride(0) * esz, S, z.stride(0), float(sample_dist), npts, L.ptr(pk.w_bf16), L.ptr(pk.tab),
+                            self.dl.offsets, d_sdf.data_ptr() + s0 * S * esz, d_n.data_ptr() + s0 * S * 3 * esz,
+                            d_rgb.data_ptr() + s0 * S * 6 * esz, rgb.data_ptr() + s0 * S * 6 * esz, fptr, L.ptr(gpanels), mptr)
+                if rg is None:
+                    with Engine._Timed("avc_render_points_bwd", npts):
+                        L.check(self.lib.avc_render_points_bwd(*bwd_args, self.MAX_BWD_WAVES, st), "avc_render_points_bwd")
+                else:
+                    rg["partial"].zero_()
+                    rg["bias"].zero_()
+                    with Engine._Timed("avc_render_points_bwd_ring", npts):
+                        L.check(self.lib.avc_render_points_bwd_ring(
+                            *bwd_args, L.ptr(rg["ctl"]), L.ptr(rg["payload"]), L.ptr(rg["partial"]), L.ptr(rg["bias"]), rg["pb"],
+                            rg["ntypes"], self.RING_CPT, self.RING_SLOTS, rg["grid"], st), "avc_render_points_bwd_ring")
+                    rg["err"] += rg["ctl"][64]
+                    if self.RING_CHECK:
+                        torch.cuda.synchronize()
+                        self.ring_stats = rg["ctl"][96:112].cpu().numpy().view(np.uint64).copy()
+                        if int(rg["ctl"][64]) != 0:
+                            raise RuntimeError("avc_render_points_bwd_ring: %d spin time-out(s), first site %d, counters %s"
+                                               % (int(rg["ctl"][64]), int(rg["ctl"][65]), self.ring_stats))
                 ns = max(1, min(256, nblk // self.WG_BLOCKS_PER_SPLIT, nblk))
                 with Engine._Timed("avc_weight_grad(all pairs)", npts):
-                    L.check(self.lib.avc_weight_grad_all(fptr, self.fwd_tiles, L.ptr(gpanels), self.grad_tiles, len(lay.pairs),
-                                                         self._pairs_host.ctypes.data, nblk, L.ptr(self._partials),
+                    L.check(self.lib.avc_weight_grad_all(fptr, self.fwd_tiles, L.ptr(gpanels), self.grad_tiles, len(pairs_host),
+                                                         pairs_host.ctypes.data, nblk, L.ptr(self._partials),
                                                          L.ptr(self._bpartials), ns, self._partials.stride(0),
                                                          self._bpartials.stride(0), st), "avc_weight_grad_all")
-                    gout += self._partials[:ns].sum(0)
-                    gbias += self._bpartials[:ns].sum(0)
+                    po, pb_ = self._partials[:ns].sum(0), self._bpartials[:ns].sum(0)
+                    if rg is not None:   # the ring products' columns of the split buffers are not written by this launch (stale): take the consumers' sums
+                        for m, (o_off, b_off) in enumerate(rg["offs"]):
+                            po[o_off:o_off + rg["partial"].shape[2]] = rg["partial"][m].sum(0)
+                            pb_[b_off:b_off + rg["bias"].shape[2]] = rg["bias"][m].sum(0)
+                    gout += po
+                    gbias += pb_
         self._panel_owner = None
         grad = torch.zeros(lay.nparam, device=self.device, dtype=torch.float32)
         grad.index_add_(0, self.dl.un_tgt, gout[self.dl.un_src] * self.dl.un_scale)
@@ -447,6 +510,8 @@ class Engine:
         # d loss / d (sdf bias) = sum of d_sdf over all points: a sum with heavy cancellation (the eikonal term pulls both
         # ways), which the bf16 panel of d_sdf gets wrong by several percent -- take it from the fp32 tensor instead
         grad[self._sdf_bias0] = d_sdf.sum()
+        if rg is not None:   # a hand-off that timed out leaves the products incomplete: make that loud without a host round trip
+            grad = torch.where(rg["err"] != 0, torch.full_like(grad, float("nan")), grad)
         return grad
 
 

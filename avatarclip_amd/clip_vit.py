@@ -178,6 +178,8 @@ class ClipVisionB32:
         self._text = None
         self._packed = {}
         self._graphed = {}
+        self._graph_busy = {}         # batch size -> a replayed forward is waiting for its backward
+        self._graph_ws = []           # packing workspaces the captured launches point at
 
     def eval(self):
         return self
@@ -245,14 +247,31 @@ class ClipVisionB32:
                 sample = torch.zeros(B, 3, RES, RES, device=self.device, dtype=torch.float32, requires_grad=True)
                 try:
                     with torch.cuda.device(self.device):     # (capture streams are created on the CURRENT device)
+                        # the captured launches bake in the pointer of the linears' packing workspace: size it for the largest linear of
+                        # this pass BEFORE the capture (no growth, i.e. no re-allocation, while launches are being recorded) ...
+                        _ws(self.device, L.load().avc_vit_workspace_bytes(B * TOKENS, 4 * WIDTH))
                         g = torch.cuda.make_graphed_callables(self._encode_image_eager, (sample,))
+                        # ... and keep that buffer alive for as long as the graphs exist: a later, larger eager call (batched scoring,
+                        # M > 128) makes _ws() allocate a new one, and dropping the old one would leave the replays writing into freed memory
+                        self._graph_ws.append(_workspace[str(self.device)])
                 except Exception as e:      # a capture that the runtime refuses must not take the training run down: eager launches
                     import logging
                     logging.warning("CLIP encode_image: HIP graph capture failed (%s: %s); launching eagerly", type(e).__name__, str(e)[:200])
                     g = False
                 self._graphed[B] = g
-            if g is not False:
-                return g(image.float())
+            # One captured instance per batch size = ONE set of static activations: a second call before the first one's backward would
+            # overwrite them (and its embedding, which aliases the graph's static output).  The reference does exactly that when
+            # add_no_texture is set (main.py:512 then :524, one image each); Runner merges the two into one B = 2 pass, other
+            # callers get the eager launches for the overlapping call.  The instance is free again once its backward has run.
+            if g is not False and not self._graph_busy.get(B, False):
+                self._graph_busy[B] = True
+                out = g(image.float())
+
+                def _release(grad, B=B):
+                    self._graph_busy[B] = False
+                    return grad
+                out.register_hook(_release)
+                return out.clone()       # (its own storage: the static output buffer is rewritten by the next replay)
         return self._encode_image_eager(image)
 
     def _encode_image_eager(self, image: torch.Tensor) -> torch.Tensor:

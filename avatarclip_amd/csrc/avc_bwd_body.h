@@ -158,9 +158,13 @@ __device__ __forceinline__ void bwd_sweeps(StageT<BWD_G>& sg, const BwdArgs& a, 
   }
   const float dsdf = a.d_sdf[i] * vmask;
   const float dsdfS = dsdf * AVC_S;   // OFF_WL0_ACC holds W_last[0,:]/(S sqrt2): undo S for the gradient use
-  {   // operand tiles with a single live feature (slot (half 0, j = 0) = feature 0): d_sdf and the constant 1 (row 0 of the last layer)
+  {   // operand tiles with one live feature (slot (half 0, j = 0) = feature 0; d_sdf: two): d_sdf and the constant 1 (row 0 of the last layer)
     b8 fs = zero_frag<b8>(), fo = zero_frag<b8>();
-    if (h == 0) { fs[0] = (__bf16)dsdf; fo[0] = (__bf16)vmask; }
+    if (h == 0) {   // d_sdf split hi + lo over two slots (both map to row 0, packing.py): 16 bits of mantissa for the one cotangent whose sums cancel heavily
+      fs[0] = (__bf16)dsdf;
+      fs[1] = (__bf16)(dsdf - (float)fs[0]);
+      fo[0] = (__bf16)vmask;
+    }
     tile_store<false>(tiles, L::G_SDF, fs, zero_frag<b8>());
     tile_store<false>(tiles, L::G_ONE, fo, zero_frag<b8>());
   }

@@ -191,6 +191,7 @@ class Engine:
     # Role-specialised backward (csrc/avc_bwd_ring.hip): the abar tiles of the middle SDF layers are handed from the backward sweeps
     # to accumulator-owning consumer workgroups of the same XCD through an L2-resident ring instead of through the G region.
     # RING_CPT = consumer workgroups per (XCD, product), RING_SLOTS = ring slots (128 KiB each for the full nets) per (XCD, product).
+    SDF_BIAS_FP32 = os.environ.get("AVC_SDF_BIAS_FP32", "0") != "0"
     RING = os.environ.get("AVC_BWD_RING", "0") != "0"
     RING_CPT = int(os.environ.get("AVC_RING_CPT", "2"))
     RING_SLOTS = int(os.environ.get("AVC_RING_SLOTS", "6"))
@@ -265,7 +266,8 @@ class Engine:
         buf = getattr(self, attr)
         n = nbytes // torch.empty(0, dtype=dtype).element_size()
         if buf is None or buf.numel() < n:
-            setattr(self, attr, None)    # release the old buffer BEFORE the larger one is allocated (peak = need, not have + need)
+            buf = None                   # release the old buffer BEFORE the larger one is allocated (peak = need, not have + need):
+            setattr(self, attr, None)    # neither the attribute nor this local may keep it alive across empty_cache()
             torch.cuda.empty_cache()
             buf = torch.empty(n, dtype=dtype, device=self.device)
             setattr(self, attr, buf)
@@ -320,6 +322,13 @@ class Engine:
             chunk, slab = self._plan_val
             if chunk < R or (self._fpanels is not None and self._fpanels.numel() >= ((R * S + 31) // 32 + 1) * self.fwd_tiles * 2048):
                 return self._plan_val  # (no driver query on the hot path: hipMemGetInfo synchronises with the device)
+        # a ray set that the buffers at hand already cover in one chunk and one slab (the silhouette mode: a different, data-dependent
+        # R every iteration, all far below the first allocation) needs no driver query either
+        nb_all = (R * S + 31) // 32 + 1
+        if (self._fpanels is not None and self._gpanels is not None and nb_all <= self.SLAB_BLOCKS
+                and self._fpanels.numel() >= nb_all * self.fwd_tiles * 2048 and self._gpanels.numel() >= nb_all * self.grad_tiles * 2048
+                and self._held_bytes() <= self.PANEL_BYTES_BUDGET):
+            return R, R
         # 80 % of what is free once the current buffers are given back (they are released before larger ones are allocated)
         budget = max(min(self.PANEL_BYTES_BUDGET, (torch.cuda.mem_get_info(self.device)[0] + self._held_bytes()) * 8 // 10), 1 << 26)
         self._plan_key = key
@@ -507,9 +516,11 @@ class Engine:
         grad.index_add_(0, self.dl.un_tgt, gout[self.dl.un_src] * self.dl.un_scale)
         if lay.gbias_size:
             grad.index_add_(0, self.dl.ub_tgt, gbias[self.dl.ub_src])
-        # d loss / d (sdf bias) = sum of d_sdf over all points: a sum with heavy cancellation (the eikonal term pulls both
-        # ways), which the bf16 panel of d_sdf gets wrong by several percent -- take it from the fp32 tensor instead
-        grad[self._sdf_bias0] = d_sdf.sum()
+        # (d loss / d (sdf bias) = sum of d_sdf over all points cancels heavily -- the eikonal term pulls both ways -- and a single bf16
+        # slot of d_sdf used to get it wrong by several percent; the tile now carries d_sdf as hi + lo, see packing.py / avc_bwd_body.h.
+        # AVC_SDF_BIAS_FP32=1 restores the old override from the fp32 tensor for A/B.)
+        if self.SDF_BIAS_FP32:
+            grad[self._sdf_bias0] = d_sdf.sum()
         if rg is not None:   # a hand-off that timed out leaves the products incomplete: make that loud without a host round trip
             grad = torch.where(rg["err"] != 0, torch.full_like(grad, float("nan")), grad)
         return grad

@@ -417,6 +417,11 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
     # last layer: rows 1..H (ybar[1:]) and row 0 (d_sdf ; second-order term through the constant-one panel)
     r1 = lambda f: (f + 1) if f < H else -1
     r0 = lambda f: 0 if f == 0 else -1
+    # the d_sdf tile carries the cotangent SPLIT in two bf16 slots (feature 0 = hi, feature 1 = d_sdf - hi; csrc/avc_bwd_body.h): both
+    # are contributions to row 0 -- d_sdf keeps 16 bits of mantissa, so the row-0 weight gradient and the sdf bias (a sum with heavy
+    # cancellation: the eikonal term pulls both ways) come out of the same product as every other row, without a special case
+    r0s = lambda f: 0 if f in (0, 1) else -1
+    assert frag_feature(0, 0, 0) == 0 and frag_feature(0, 0, 1) == 1
     # (its input [hs | pe] = the adjacent panels HS, H0 resp. GBHS, GB0: one product over ST + 2 column tiles each)
     assert P["H0"] == P["HS"] + ST and P["GB0"] == P["GBHS"] + ST
 
@@ -426,7 +431,7 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
     hs_scale = lambda t_b: 1 / (SQ2 * S_B2) if t_b < ST else 1 / SQ2
     # rows 1..H (DFEAT tiles) and row 0 (the SDF tile right behind them) in ONE product: [hs | pe] is read once for both
     assert P["SDF"] == P["DFEAT"] + HT
-    rows_last = lambda f: r1(f) if f < 32 * HT else r0(f - 32 * HT)
+    rows_last = lambda f: r1(f) if f < 32 * HT else r0s(f - 32 * HT)
     add_pair(P["DFEAT"], HT + 1, P["HS"], ST + 2, ll, rows_last, last_cols(True), scale=hs_scale, bname=bl)
     add_pair(P["ONE"], 1, P["GBHS"], ST + 2, ll, r0, last_cols(False), scale=1 / SQ2)
     # colour

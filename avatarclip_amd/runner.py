@@ -593,7 +593,7 @@ class Runner:
             progress = (self.iter_step - self.warm_up_end) / (self.end_iter - self.warm_up_end)
             learning_factor = (np.cos(np.pi * progress) + 1.0) * 0.5 * (1 - alpha) + alpha
         for g in self.optimizer.param_groups:
-            g["lr"] = self.learning_rate * learning_factor
+            g["lr"] = float(self.learning_rate * learning_factor)   # (a Python float: a numpy scalar here would make the checkpoint more than tensors and plain containers)
 
     def file_backup(self):
         dir_lis = self.conf.get("general.recording", default=[])
@@ -610,12 +610,27 @@ class Runner:
 
     def _torch_load(self, path):
         """checkpoints of this stage hold tensors, the optimizer's plain containers and an int: the tensors-only unpickler reads
-        them without executing code from the file; anything else falls back to the reference's plain torch.load with a warning"""
+        them without executing code from the file.  A file it rejects is loaded with the full unpickler -- which executes code from
+        the file, as the reference's plain torch.load does -- only with the same explicit opt-in as the other loaders
+        (AVC_ALLOW_UNSAFE_PICKLE=1: clip_vit.load_state_dict, smpl_lbs.load_smpl_arrays); I/O errors are not retried."""
+        import pickle
         try:
-            return torch.load(path, map_location=self.device, weights_only=True)
-        except Exception as e:
-            logging.warning("%s is not a tensors-only checkpoint (%s): loading it with the full unpickler, which executes code from "
-                            "the file", path, type(e).__name__)
+            # (numpy scalars -- the learning rate the reference's update_learning_rate leaves in the optimizer's param groups -- are
+            # data, not code: allow-listed for the tensors-only unpickler)
+            safe = [np.dtype, type(np.dtype(np.float64)), type(np.dtype(np.float32)), type(np.dtype(np.int64))]
+            try:
+                from numpy._core.multiarray import scalar as np_scalar       # numpy 2
+            except ImportError:
+                from numpy.core.multiarray import scalar as np_scalar        # numpy 1
+            # (files written under numpy 1 -- the reference's shipped checkpoint -- name it by its old module path)
+            safe += [np_scalar, (np_scalar, "numpy.core.multiarray.scalar"), (np_scalar, "numpy._core.multiarray.scalar")]
+            with torch.serialization.safe_globals(safe):
+                return torch.load(path, map_location=self.device, weights_only=True)
+        except pickle.UnpicklingError as e:
+            if os.environ.get("AVC_ALLOW_UNSAFE_PICKLE") != "1":
+                raise RuntimeError("%s is not a tensors-only checkpoint (%s); loading it would execute pickled code (set "
+                                   "AVC_ALLOW_UNSAFE_PICKLE=1 to allow that)" % (path, str(e)[:200])) from e
+            logging.warning("%s is not a tensors-only checkpoint: loading it with the full unpickler (AVC_ALLOW_UNSAFE_PICKLE=1)", path)
             return torch.load(path, map_location=self.device, weights_only=False)
 
     def load_checkpoint(self, checkpoint_name):

@@ -53,13 +53,14 @@ def random_state_dict(seed: int = 0, dtype=torch.float32) -> Dict[str, torch.Ten
 
 
 def outlier_state_dict(seed: int = 0, n_channels: int = 8, gain: float = 30.0, n_fc_rows: int = 4, fc_gain: float = 20.0,
-                       ln_blocks=()):
+                       ln_blocks=(), ln_gain=None):
     """An OFFLINE PROXY for the dynamic range of trained CLIP weights (the real ViT-B-32.pt cannot be fetched here): the seeded
     state dict with the signature of trained ViTs' "massive activation" channels.
       * default: `n_channels` residual channels are inflated `gain` times in the class / CLS-position embedding and in the ln_pre
         gain, so the CLS token enters -- and, through the residual connections, stays in -- every block with a handful of channels
         30x above the median; `n_fc_rows` rows of every mlp.c_fc are `fc_gain` times larger.
-      * ln_blocks = range(12): additionally the ln_1 / ln_2 gains of those channels are inflated in the listed blocks.  With all 24
+      * ln_blocks = range(12): additionally the ln_1 / ln_2 gains of those channels are inflated (`ln_gain` times, default = `gain`)
+        in the listed blocks.  With all 24
         gains at 30x the seeded (untrained) network becomes chaotic in its INPUT: merely rounding the linear operands to bf16 on the
         CPU (fp32 accumulation) changes d cos / d pixels by O(1) while the embedding moves by 3e-4 (tests/test_gpu_clip.py prints it).
     Not a substitute for the real weights (test_real_openai_weights_when_supplied stays the real check); it shows which tolerance
@@ -78,7 +79,7 @@ def outlier_state_dict(seed: int = 0, n_channels: int = 8, gain: float = 30.0, n
         if i in ln_blocks:
             for n in ("ln_1.weight", "ln_2.weight"):
                 sd[p + n] = sd[p + n].clone()
-                sd[p + n][ch] *= gain
+                sd[p + n][ch] *= gain if ln_gain is None else ln_gain
         rows = torch.randperm(4 * WIDTH, generator=g)[:n_fc_rows]
         sd[p + "mlp.c_fc.weight"] = sd[p + "mlp.c_fc.weight"].clone()
         sd[p + "mlp.c_fc.weight"][rows] *= fc_gain

@@ -120,6 +120,43 @@ def test_training_call_replayed_as_hip_graphs_is_bit_identical_to_eager_launches
 
 
 @gpu
+def test_two_calls_before_one_backward_do_not_share_the_captured_instance(monkeypatch):
+    """The reference's own pattern with add_no_texture (main.py:512 then :524: two encode_image calls of one image each, ONE
+    loss.backward()): a captured HIP graph has one set of static activations and one static output, so the second call must not go
+    through the instance that is still waiting for its backward.  Embeddings and pixel gradients of both calls equal the eager
+    launches bit for bit; a later scoring call that needs a larger packing workspace must not free the one the graphs write into;
+    after the backward the instance is free again."""
+    from avatarclip_amd import clip_vit as V
+    dev = torch.device("cuda")
+    model = V.ClipVisionB32(C.random_state_dict(0), dev)
+    text = torch.randn(1, 512, generator=torch.Generator().manual_seed(5)).to(dev)
+    imgs = [torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(20 + k)).to(dev) for k in range(2)]
+    res = {}
+    for graph in (True, False):
+        monkeypatch.setattr(V, "TRAIN_GRAPH", graph)
+        for rnd in range(2):
+            xs = [im.clone().requires_grad_(True) for im in imgs]
+            es = [model.encode_image(x) for x in xs]
+            if graph:
+                assert model._graph_busy.get(1) is True           # the first call holds the instance, the second ran eagerly
+            loss = sum(1 - torch.cosine_similarity(e.mean(0), text.mean(0), dim=0) for e in es)
+            loss.backward()
+            if graph:
+                assert model._graph_busy.get(1) is False
+                if rnd == 0:
+                    with torch.no_grad():                         # 8 images: the packed scoring pipeline; the eager linears of a
+                        model.encode_image(torch.randn(8, 3, 224, 224, device=dev))     # 4-image gradient call grow the workspace
+                    big = torch.randn(4, 3, 224, 224, device=dev, requires_grad=True)
+                    model.encode_image(big).sum().backward()
+            res[(graph, rnd)] = ([e.detach().clone() for e in es], [x.grad.clone() for x in xs])
+    for rnd in range(2):
+        for k in range(2):
+            assert torch.equal(res[(True, rnd)][0][k], res[(False, rnd)][0][k]), (rnd, k)
+            assert torch.equal(res[(True, rnd)][1][k], res[(False, rnd)][1][k]), (rnd, k)
+    assert not torch.equal(res[(True, 0)][0][0], res[(True, 0)][0][1])
+
+
+@gpu
 def test_encode_image_matches_oracle():
     from avatarclip_amd import clip_vit as V
     dev = torch.device("cuda")
@@ -145,20 +182,24 @@ def test_encode_image_matches_oracle():
 
 
 @gpu
-@pytest.mark.parametrize("harsh", [False, True])
-def test_encode_image_with_outlier_channels_matches_oracle(harsh):
-    """trained CLIP ViTs carry a handful of residual channels / c_fc rows tens of times above the median, which the
-    N(0, sigma) weights of the test above do not.  Same comparison on oracle/clip_vit_oracle.outlier_state_dict:
-      harsh = False: 8 residual channels x 30 (class / CLS-position embedding, ln_pre gain: massive CLS-token channels that persist
-                     through all blocks), 4 c_fc rows x 20 per block -> the tolerances of the seeded test hold unchanged;
-      harsh = True : additionally ALL 24 block LayerNorm gains x 30 on those channels.  The forward quantities the loss uses
-                     (embedding, cos(emb, text)) still hold to 1e-3; the pixel gradient of that untrained network is chaotic under
-                     ANY bf16 rounding of operands (CPU statement printed beside the kernel's), so it is compared with the CPU
-                     bf16-operand restatement at a loose bound instead of with the fp32 oracle.
+@pytest.mark.parametrize("variant", ["channels", "ln4", "ln30"])
+def test_encode_image_with_outlier_channels_matches_oracle(variant):
+    """trained CLIP ViTs carry a handful of residual channels / c_fc rows tens of times above the median, which
+    the N(0, sigma) weights of the test above do not.  Same comparison on oracle/clip_vit_oracle.outlier_state_dict:
+      channels: 8 residual channels x 30 (class / CLS-position embedding, ln_pre gain: massive CLS-token channels that persist
+                through all blocks), 4 c_fc rows x 20 per block -> the tolerances of the seeded test hold unchanged;
+      ln4     : additionally ALL 24 block LayerNorm gains x 4 on those channels.  Rounding the linear operands to bf16 ON THE CPU
+                moves the pixel gradient of this network by 2.8 % (encode_image_bf16_operands vs fp32; 0.5 % without the gains):
+                still a well-conditioned map, so the kernel's gradient is asserted against BOTH statements -- within 6 % of fp32
+                (twice what bf16 operands alone do) and within 5 % of the CPU bf16-operand statement;
+      ln30    : the gains x 30.  The untrained network is then chaotic in its input -- a SINGLE block with such gains already moves
+                the CPU bf16-operand gradient by 64 % against fp32 (all twelve: 430 %) while the embedding moves by 3e-4 -- so no
+                statement about the gradient can be tested there and none is made: only the forward quantities the loss uses
+                (embedding, cos(emb, text)) are asserted, the gradient numbers are printed.
     The bounds are stated in DESIGN.md section 2 (main.py:259,512)."""
     from avatarclip_amd import clip_vit as V
     dev = torch.device("cuda")
-    sd = C.outlier_state_dict(0, ln_blocks=range(12) if harsh else ())
+    sd = C.outlier_state_dict(0, ln_blocks=() if variant == "channels" else range(12), ln_gain=4.0 if variant == "ln4" else None)
     model = V.ClipVisionB32(sd, dev)
     g = torch.Generator().manual_seed(1)
     img = torch.randn(2, 3, 224, 224, generator=g)
@@ -176,14 +217,19 @@ def test_encode_image_with_outlier_channels_matches_oracle(harsh):
     sim = torch.cosine_similarity(emb, ref, dim=-1).min().item()
     rel = ((gx - gr).norm() / gr.norm()).item()
     rel_q = ((gq - gr).norm() / gr.norm()).item()          # what bf16 operands alone do to this network (CPU, fp32 accumulate)
-    print("OUTLIER harsh=%s  embedding cosine %.6f (cpu bf16-operand restatement %.6f)  |d cos| %.2e (%.2e)  pixel-grad rel err %.3e (%.3e)"
-          % (harsh, sim, torch.cosine_similarity(emq, ref, dim=-1).min().item(), abs(cos - cos_r), abs(cos_q - cos_r), rel, rel_q))
+    rel_kq = ((gx - gq).norm() / gq.norm()).item()         # the kernel against that CPU statement
+    print("OUTLIER %s  embedding cosine %.6f (cpu bf16-operand restatement %.6f)  |d cos| %.2e (%.2e)  pixel-grad rel err vs fp32 %.3e "
+          "(cpu bf16 operands vs fp32 %.3e, kernel vs cpu bf16 operands %.3e)"
+          % (variant, sim, torch.cosine_similarity(emq, ref, dim=-1).min().item(), abs(cos - cos_r), abs(cos_q - cos_r), rel, rel_q, rel_kq))
     assert torch.isfinite(emb).all() and torch.isfinite(gx).all()
-    if not harsh:
+    if variant == "channels":
         assert sim > 0.9995 and abs(cos - cos_r) < 1e-3 and rel < 3e-2
+    elif variant == "ln4":
+        assert sim > 0.9995 and abs(cos - cos_r) < 1e-3
+        assert rel_q < 4e-2, "the CPU statement itself: this variant is supposed to be well conditioned"
+        assert rel < 6e-2 and rel_kq < 5e-2
     else:
         assert sim > 0.999 and abs(cos - cos_r) < 2e-3
-        assert rel < max(2.0 * rel_q, 0.2), "the kernel's pixel gradient is further from fp32 than bf16 operands explain"
 
 
 def _full_state_dict():

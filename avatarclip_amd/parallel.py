@@ -16,6 +16,8 @@ def init_from_env(backend=None):
     # under a launcher (torch.distributed.run sets RANK and WORLD_SIZE) the process group is created for ONE rank too: the
     # single-rank job then runs the same broadcast / flat-bucket all-reduce path over RCCL as the 8-rank one
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if world > 1:
+        pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if (world > 1 or launched) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -27,6 +29,26 @@ def init_from_env(backend=None):
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
+
+
+def pin_host_threads(local_rank, local_world):
+    """N launch-heavy host processes on one node (639 launches per step each at 512^2): give every rank its own slice of the cores
+    (intra-op torch threads = the slice, CPU affinity = the slice) instead of N x all-cores thread pools fighting each other.
+    AVC_PIN_THREADS=0 leaves both alone."""
+    if os.environ.get("AVC_PIN_THREADS", "1") == "0" or local_world <= 1:
+        return None
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except AttributeError:          # not on this platform
+        return None
+    per = max(1, len(cores) // local_world)
+    mine = cores[(local_rank % local_world) * per:(local_rank % local_world + 1) * per] or cores
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    torch.set_num_threads(max(1, min(len(mine), 16)))
+    return mine
 
 
 def is_on():

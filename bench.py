@@ -293,6 +293,12 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if os.environ.get("AVC_SINGLE_DEVICE"):
+            # N processes on ONE device (the 1-GPU development rig): with the default 4 hardware queues per process, 8 processes
+            # oversubscribe the queue slots, the scheduler starts preempting wavefronts by context save / restore, and launches
+            # died with HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION in 2 of 5 such runs.  One process per GPU -- the
+            # product's layout -- never oversubscribes.
+            env.setdefault("GPU_MAX_HW_QUEUES", "2")
         sys.exit(subprocess.call(cmd, env=env))
 
     from avatarclip_amd import parallel

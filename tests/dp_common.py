@@ -49,6 +49,8 @@ def build_runner(device, res, spp, use_oracle_kernels):
 def worker(rank, world, port, out, device_kind, res, spp):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       AVC_DIST_BACKEND="gloo")
+    if device_kind == "cuda":   # all ranks share device 0: keep the hardware queues from being oversubscribed (see bench.py's spawner)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
     from avatarclip_amd import parallel
     parallel.init_from_env(backend="gloo")
     device = torch.device("cuda", 0) if device_kind == "cuda" else torch.device("cpu")   # all ranks share device 0 (development aid)
@@ -57,10 +59,14 @@ def worker(rank, world, port, out, device_kind, res, spp):
     w0 = [p.detach().cpu().clone() for p in r.params_to_train]
     loss = r.train_clip_iteration(0)
     v = r.last_view
-    out[rank] = dict(eye=np.asarray(v.eye), at=np.asarray(v.at), loss=float(loss), data_seed=r.data_seed, w0=w0,
-                     grads=[p.grad.detach().cpu().clone() for p in r.params_to_train],
-                     params=[p.detach().cpu().clone() for p in r.params_to_train],
-                     bucket_is_grad=all(p.grad.data_ptr() == g.data_ptr() for p, g in zip(r.params_to_train, r.grad_bucket.views)))
+    res_ = dict(eye=np.asarray(v.eye), at=np.asarray(v.at), loss=float(loss), data_seed=r.data_seed, w0=w0,
+                grads=[p.grad.detach().cpu().clone() for p in r.params_to_train],
+                params=[p.detach().cpu().clone() for p in r.params_to_train],
+                bucket_is_grad=all(p.grad.data_ptr() == g.data_ptr() for p, g in zip(r.params_to_train, r.grad_bucket.views)))
+    if isinstance(out, str):    # a directory: one file per rank (eight ranks answering a Manager at once overran its listener)
+        torch.save(res_, os.path.join(out, "rank%d.pt" % rank))
+    else:
+        out[rank] = res_
     parallel.barrier()
     torch.distributed.destroy_process_group()
 

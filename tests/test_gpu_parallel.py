@@ -12,28 +12,38 @@ gpu = pytest.mark.gpu
 
 
 @gpu
-def test_two_ranks_on_the_hip_path_equal_single_gpu_accumulation():
-    world, res, spp = 2, 32, 32
-    mgr = mp.Manager()
-    out = mgr.dict()
-    mp.spawn(worker, args=(world, free_port(), out, "cuda", res, spp), nprocs=world, join=True)
-    a, b = out[0], out[1]
-    assert np.abs(a["eye"] - b["eye"]).max() > 1e-3, "both ranks drew the same camera"
-    assert a["bucket_is_grad"] and b["bucket_is_grad"]
-    for wa, wb, ga, gb, pa, pb in zip(a["w0"], b["w0"], a["grads"], b["grads"], a["params"], b["params"]):
-        assert torch.equal(wa, wb) and torch.equal(ga, gb) and torch.equal(pa, pb)
-    w0, mean_grads, losses = single_process_accumulation("cuda", world, res, spp, [a["data_seed"], b["data_seed"]])
-    assert abs(losses[0] - a["loss"]) < 1e-5 and abs(losses[1] - b["loss"]) < 1e-5, (losses, a["loss"], b["loss"])
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_on_the_hip_path_equal_single_gpu_accumulation(world, tmp_path):
+    """world = 8 is the size BASELINE config 3 runs at: eight processes, eight libavc loads and engines on one device, eight different
+    cameras, one flat bucket whose mean must equal one process accumulating the same eight views (SURVEY 8e's parity statement)."""
+    import os
+    res, spp = 32, 32
+    mp.spawn(worker, args=(world, free_port(), str(tmp_path), "cuda", res, spp), nprocs=world, join=True)
+    rs = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % k), weights_only=False) for k in range(world)]
+    a = rs[0]
+    eyes = np.stack([r["eye"] for r in rs])
+    d = np.abs(eyes[:, None] - eyes[None]).max(-1) + np.eye(world)
+    assert d.min() > 1e-3, "two ranks drew the same camera"
+    assert len({r["data_seed"] for r in rs}) == world
+    for b in rs:
+        assert b["bucket_is_grad"]
+        for wa, wb, ga, gb, pa, pb in zip(a["w0"], b["w0"], a["grads"], b["grads"], a["params"], b["params"]):
+            assert torch.equal(wa, wb) and torch.equal(ga, gb) and torch.equal(pa, pb)
+    w0, mean_grads, losses = single_process_accumulation("cuda", world, res, spp, [r["data_seed"] for r in rs])
+    for k in range(world):
+        assert abs(losses[k] - rs[k]["loss"]) < 1e-5, (k, losses, rs[k]["loss"])
     gn = torch.cat([g.reshape(-1) for g in mean_grads]).norm()
     for g1, g2 in zip(mean_grads, a["grads"]):
         assert (g1 - g2).norm() <= 1e-4 * (g1.norm() + 1e-3 * gn)
 
 
 @gpu
-def test_bench_spawns_its_own_ranks_and_reports_the_whole_job():
-    """`python bench.py --gpus 2` with no WORLD_SIZE starts the two ranks itself (the driver's contract); both ranks share device 0
-    here (AVC_SINGLE_DEVICE + gloo, the development path for a 1-GPU box).  The JSON line must say n_gpus = 2 and count the rays of
-    BOTH ranks; without AVC_SINGLE_DEVICE the same command must refuse to run on a box with one device."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_spawns_its_own_ranks_and_reports_the_whole_job(world):
+    """`python bench.py --gpus N` with no WORLD_SIZE starts the N ranks itself (the driver's contract); all ranks share device 0 here
+    (AVC_SINGLE_DEVICE + gloo, the development path for a 1-GPU box).  N = 8 = the driver's largest run: eight host processes, eight
+    CLIP graph captures, eight hipFuncSetAttribute paths at once.  The JSON line must say n_gpus = N and count the rays of ALL ranks;
+    without AVC_SINGLE_DEVICE the same command must refuse to run on a box with one device."""
     import json
     import os
     import subprocess
@@ -42,14 +52,15 @@ def test_bench_spawns_its_own_ranks_and_reports_the_whole_job():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, AVC_SINGLE_DEVICE="1", AVC_DIST_BACKEND="gloo")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None)
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--res", "64", "--small", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--res", "64", "--small", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 1
-    assert abs(out["value"] - 2 * 64 * 64 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
-    if torch.cuda.device_count() < 2:
+    assert out["n_gpus"] == world and out["scaling"] == "weak" and out["steps"] == 2
+    assert out["config"]["collective"] == "gloo, %d rank(s)" % world
+    assert abs(out["value"] - world * 64 * 64 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+    if torch.cuda.device_count() < world and world == 2:
         env2 = dict(os.environ); env2.pop("AVC_SINGLE_DEVICE", None); env2.pop("WORLD_SIZE", None); env2.pop("RANK", None)
         r2 = subprocess.run(cmd, env=env2, capture_output=True, text=True, timeout=120, cwd=root)
         assert r2.returncode != 0 and "device" in (r2.stderr + r2.stdout)

@@ -3,11 +3,14 @@ queue.  A `tensor.to(device)` from pageable memory is a blocking copy ordered be
 stream: one of them after the render kernels makes the host wait for the render and then launch the ~1000 small CLIP kernels
 with the GPU idling in between.  Here the values go through a ring of pinned staging rows (non-blocking copies; a row is
 reused only after the event recorded behind its copy has completed) and constants are uploaded once per device."""
+import threading
+
 import numpy as np
 import torch
 
 _consts = {}
 _rings = {}
+_lock = threading.Lock()     # the view of the next iteration is prepared on a helper thread (Runner.prefetch_view)
 
 
 def const(values, device, dtype=torch.float32):
@@ -32,8 +35,9 @@ class _Ring:
 
     def put(self, a, dtype):
         n = a.size
-        slot = self.i % self.SLOTS
-        self.i += 1
+        with _lock:
+            slot = self.i % self.SLOTS
+            self.i += 1
         ev = self.events[slot]
         if ev is not None:
             ev.synchronize()
@@ -54,7 +58,8 @@ def upload(values, device, dtype=torch.float32):
     if device.type != "cuda" or a.size > _Ring.WIDTH:
         return torch.from_numpy(a).to(device=device, dtype=dtype)
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
-    ring = _rings.get(key)
-    if ring is None:
-        ring = _rings[key] = _Ring(device)
+    with _lock:
+        ring = _rings.get(key)
+        if ring is None:
+            ring = _rings[key] = _Ring(device)
     return ring.put(a, dtype)

@@ -359,6 +359,8 @@ class Runner:
                 self.save_checkpoint()
             self._validation_hooks(clip_stage=True)
             self.update_learning_rate()
+            if iter_i + 1 < res_step:
+                self.prefetch_view(iter_i + 1)
         if self.writer is not None:
             self.writer.flush()
 
@@ -416,16 +418,51 @@ class Runner:
         the persistent MLP kernels -- profiles/r03_side_stream.txt.)  AVC_OVERLAP_HEAD=0: everything on one stream."""
         if self.device.type != "cuda" or os.environ.get("AVC_OVERLAP_HEAD", "1") == "0":
             return self.make_view(iter_i, camera)
+        fut, self._view_future = getattr(self, "_view_future", None), None
+        if fut is not None:
+            view = fut[1].result()              # (always collected: the helper thread must not run into the next make_view)
+            if camera is None and fut[0] == iter_i:
+                return self._adopt_view(view)
+        return self._make_view_side(iter_i, camera)
+
+    # ---- the next iteration's view, prepared while this iteration's kernels are being launched (silhouette mode)
+    def prefetch_view(self, iter_i):
+        """Start make_view(iter_i) on a helper thread + the side stream.  The silhouette mode's ray set has a data-dependent size:
+        make_view brings two numbers to the host (pixel counts -> ray-grid size -> ray count), and each round trip waits until its
+        few small kernels have found room beside the previous iteration's persistent MLP kernels -- 1.3 ms per iteration of a host
+        that is the bottleneck of this mode (7 000 - 12 544 rays: 6.5 ms per iteration, of which the GPU's MLP kernels take ~3).  The
+        view depends on nothing the optimiser writes, so it can be prepared one iteration ahead; the helper thread does the waiting.
+        The camera is drawn HERE, in the caller's thread, at the point where the next iteration would draw it anyway: the numpy
+        draw order of main.py:348-440 is unchanged.  Called by train_clip() / bench.py after each iteration; a no-op outside the
+        silhouette mode and on the CPU.  OPT-IN (AVC_PREFETCH_VIEW=1): measured, it does not pay -- the round trips wait because the
+        GPU is busy with the iteration's ~690 small launches, not because the host idles (6.8 vs 6.2 ms per iteration at 7 000 rays,
+        9.1 vs 9.1 at 12 544: profiles/r04_ab_kernels.txt)."""
+        if (not self.use_silhouettes or self.device.type != "cuda" or os.environ.get("AVC_PREFETCH_VIEW", "0") != "1"
+                or os.environ.get("AVC_OVERLAP_HEAD", "1") == "0" or getattr(self, "_view_future", None) is not None):
+            return
+        if getattr(self, "_view_pool", None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._view_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="avc-view")
+        camera = self.sample_camera(iter_i)
+        self._view_future = (iter_i, self._view_pool.submit(self._make_view_side, iter_i, camera, False))
+
+    def _make_view_side(self, iter_i, camera, adopt=True):
         main = torch.cuda.current_stream(self.device)
         side = getattr(self, "_side_stream", None)
         if side is None:
             side = self._side_stream = torch.cuda.Stream(device=self.device)
             side.wait_stream(main)       # first use: whatever initialisation is still in flight on the main stream
-        with torch.cuda.stream(side):
+        with torch.cuda.device(self.device), torch.cuda.stream(side):
             view = self.make_view(iter_i, camera)
-            ready = torch.cuda.Event()
-            ready.record(side)
-        main.wait_event(ready)
+            view.ready = torch.cuda.Event()
+            view.ready.record(side)
+        return self._adopt_view(view) if adopt else view
+
+    def _adopt_view(self, view):
+        """the consuming (main) stream waits for the view's event; every tensor of the view is registered with it so that the
+        caching allocator does not hand the memory back to the side stream while main-stream kernels still read it"""
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(view.ready)
         for t in vars(view).values():
             if torch.is_tensor(t) and t.is_cuda:
                 t.record_stream(main)

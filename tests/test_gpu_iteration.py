@@ -293,6 +293,41 @@ def test_train_clip_iteration_with_silhouette_rays_and_background_augmentation()
 
 
 @gpu
+def test_prefetched_views_keep_the_draw_order_and_the_losses(monkeypatch):
+    """Runner.prefetch_view (the next iteration's silhouette view prepared on a helper thread + side stream while this iteration is
+    being launched): same cameras, same ray sets, same background choices and the same losses as the run that prepares every view at
+    the start of its own iteration -- the numpy draw order of main.py:348-440 is untouched."""
+    import bench
+    from avatarclip_amd.runner import Runner
+
+    def run(prefetch):
+        monkeypatch.setenv("AVC_PREFETCH_VIEW", "1" if prefetch else "0")
+        conf = bench.make_conf(256, 32, small=True)
+        conf.put("train.use_silhouettes", True)
+        conf.put("train.max_ray_num", 3000)
+        conf.put("train.warm_up_end", 0)
+        torch.manual_seed(0)
+        np.random.seed(3)
+        r = Runner(None, mode="train_clip", conf=conf, device=torch.device("cuda"))
+        r.init_clip()
+        r.init_smpl()
+        r.update_learning_rate()
+        rec = []
+        for i in range(6):
+            loss = r.train_clip_iteration(i)
+            rec.append((np.asarray(r.last_view.eye).copy(), int(r.last_stats["rays"]), float(loss)))
+            r.update_learning_rate()
+            r.prefetch_view(i + 1)
+        assert (getattr(r, "_view_future", None) is not None) == prefetch      # (opt-in: AVC_PREFETCH_VIEW=1)
+        return rec
+    a, b = run(True), run(False)
+    for (e1, n1, l1), (e2, n2, l2) in zip(a, b):
+        assert np.array_equal(e1, e2) and n1 == n2
+    assert abs(a[0][2] - b[0][2]) < 1e-5
+    assert all(abs(x[2] - y[2]) < 5e-2 * max(1.0, abs(y[2])) for x, y in zip(a, b))     # (later iterations: fp32 summation order of the gradient scatter)
+
+
+@gpu
 @pytest.mark.parametrize("flags", [dict(add_no_texture=False, texture_cast_light=False, use_face_prompt=False, use_back_prompt=False),
                                    dict(add_no_texture=False, texture_cast_light=True, use_face_prompt=True, use_back_prompt=False),
                                    dict(add_no_texture=True, texture_cast_light=False, use_face_prompt=False, use_back_prompt=True)])

@@ -511,28 +511,32 @@ __device__ __forceinline__ float sdf_only(ST& sg, const h8* __restrict__ Wf, TP 
       h8 pef[3];
       pe_to_frags_f16(pe, x, h, pef);
       layer_s1<h8, 3, N::HT>(sg, Wf, o.v[OFF_W0], nxt<N, OFF_WM0>(sg, Wf, o), pef, AVC_EPI(
+        if constexpr (AVC_SDF_F16_ACT != 0) { softplus_frags_f16(acc, h1[2 * t], h1[2 * t + 1]); } else {
         float a[16];
         _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r]);
-        acc_to_frags(a, h1[2 * t], h1[2 * t + 1]);
+        acc_to_frags(a, h1[2 * t], h1[2 * t + 1]); }
       ), NoHook{}, TabBias{T + o.v[OFF_B0], h});
     }
     if constexpr (N::NMID == 2) {
       h8 hm0[N::HK];
       layer_s1<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wf, o), h1, AVC_EPI(
+        if constexpr (AVC_SDF_F16_ACT != 0) { softplus_frags_f16(acc, hm0[2 * t], hm0[2 * t + 1]); } else {
         float a[16];
         _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r]);
-        acc_to_frags(a, hm0[2 * t], hm0[2 * t + 1]);
+        acc_to_frags(a, hm0[2 * t], hm0[2 * t + 1]); }
       ), NoHook{}, TabBias{T + o.v[OFF_BM0], h});
       layer_s1<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wf, o), hm0, AVC_EPI(
+        if constexpr (AVC_SDF_F16_ACT != 0) { softplus_frags_f16(acc, hlast[2 * t], hlast[2 * t + 1]); } else {
         float a[16];
         _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r]);
-        acc_to_frags(a, hlast[2 * t], hlast[2 * t + 1]);
+        acc_to_frags(a, hlast[2 * t], hlast[2 * t + 1]); }
       ), NoHook{}, TabBias{T + o.v[OFF_BM1], h});
     } else {
       layer_s1<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wf, o), h1, AVC_EPI(
+        if constexpr (AVC_SDF_F16_ACT != 0) { softplus_frags_f16(acc, hlast[2 * t], hlast[2 * t + 1]); } else {
         float a[16];
         _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r]);
-        acc_to_frags(a, hlast[2 * t], hlast[2 * t + 1]);
+        acc_to_frags(a, hlast[2 * t], hlast[2 * t + 1]); }
       ), NoHook{}, TabBias{T + o.v[OFF_BM0], h});
     }
   }

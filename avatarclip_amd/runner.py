@@ -359,8 +359,6 @@ class Runner:
                 self.save_checkpoint()
             self._validation_hooks(clip_stage=True)
             self.update_learning_rate()
-            if iter_i + 1 < res_step:
-                self.prefetch_view(iter_i + 1)
         if self.writer is not None:
             self.writer.flush()
 
@@ -406,6 +404,15 @@ class Runner:
                                      rays_o=rays_o, rays_d=rays_d, near=near, far=far, true_rgb=true_rgb, mask=mask,
                                      dilated_mask=dilated_mask, sel_idx=sel_idx)
 
+    def _take_view(self, iter_i, camera=None):
+        """the view of this iteration: the one prefetch_view prepared, or a fresh one (silhouette mode: on the side stream)"""
+        fut, self._view_future = getattr(self, "_view_future", None), None
+        if fut is not None:
+            view = fut[1].result()              # (always collected: the helper thread must not run into the next make_view)
+            if camera is None and fut[0] == iter_i:
+                return self._adopt_view(view)
+        return self.make_view_on_side_stream(iter_i, camera) if self.use_silhouettes else self.make_view(iter_i, camera)
+
     def make_view_on_side_stream(self, iter_i, camera=None):
         """make_view for the silhouette mode, enqueued on a second HIP stream.  The ray set of that mode has a data-dependent size, so
         make_view has to bring two numbers to the host (dataset.gen_rays_silhouettes); on the main stream each of those round trips
@@ -418,40 +425,41 @@ class Runner:
         the persistent MLP kernels -- profiles/r03_side_stream.txt.)  AVC_OVERLAP_HEAD=0: everything on one stream."""
         if self.device.type != "cuda" or os.environ.get("AVC_OVERLAP_HEAD", "1") == "0":
             return self.make_view(iter_i, camera)
-        fut, self._view_future = getattr(self, "_view_future", None), None
-        if fut is not None:
-            view = fut[1].result()              # (always collected: the helper thread must not run into the next make_view)
-            if camera is None and fut[0] == iter_i:
-                return self._adopt_view(view)
         return self._make_view_side(iter_i, camera)
 
-    # ---- the next iteration's view, prepared while this iteration's kernels are being launched (silhouette mode)
-    def prefetch_view(self, iter_i):
-        """Start make_view(iter_i) on a helper thread + the side stream.  The silhouette mode's ray set has a data-dependent size:
-        make_view brings two numbers to the host (pixel counts -> ray-grid size -> ray count), and each round trip waits until its
-        few small kernels have found room beside the previous iteration's persistent MLP kernels -- 1.3 ms per iteration of a host
-        that is the bottleneck of this mode (7 000 - 12 544 rays: 6.5 ms per iteration, of which the GPU's MLP kernels take ~3).  The
-        view depends on nothing the optimiser writes, so it can be prepared one iteration ahead; the helper thread does the waiting.
-        The camera is drawn HERE, in the caller's thread, at the point where the next iteration would draw it anyway: the numpy
-        draw order of main.py:348-440 is unchanged.  Called by train_clip() / bench.py after each iteration; a no-op outside the
-        silhouette mode and on the CPU.  OPT-IN (AVC_PREFETCH_VIEW=1): measured, it does not pay -- the round trips wait because the
-        GPU is busy with the iteration's ~690 small launches, not because the host idles (6.8 vs 6.2 ms per iteration at 7 000 rays,
-        9.1 vs 9.1 at 12 544: profiles/r04_ab_kernels.txt)."""
-        if (not self.use_silhouettes or self.device.type != "cuda" or os.environ.get("AVC_PREFETCH_VIEW", "0") != "1"
-                or os.environ.get("AVC_OVERLAP_HEAD", "1") == "0" or getattr(self, "_view_future", None) is not None):
+    # ---- the next iteration's view, prepared beside this iteration's CLIP pass
+    def prefetch_view(self, iter_i, after=None):
+        """Start make_view(iter_i) for the NEXT iteration on the side stream.  The view depends on nothing the optimiser writes, and
+        its ~100-140 small kernels (camera, prior rasterisation, rays; 1.0-1.3 ms of GPU time) fit beside the only other stretch of
+        small kernels in the iteration -- the CLIP pass, 24-96 workgroups on a 256-CU chip -- whereas beside the persistent MLP kernels
+        nothing becomes resident (profiles/r03_side_stream.txt, r04_ab_kernels.txt).  clip_loss() calls this right before it launches
+        CLIP, when every numpy draw of the current iteration (background, light, ambience) has been made: the camera of iteration
+        i + 1 is drawn HERE, in the caller's thread, exactly where main.py:348-358 would draw it next, so the draw order is unchanged.
+        `after` = an event on the main stream the side stream waits for (the end of the render + shading work), so that the view's
+        kernels start when the GPU reaches CLIP.  In silhouette mode make_view makes two round trips to the host (pixel counts -> ray
+        grid -> ray count): a helper thread does that waiting.  Injected cameras (tests) bypass it.  OPT-IN (AVC_PREFETCH_VIEW=1):
+        measured, the two streams of small kernels hardly overlap -- 6.3 vs 6.6 ms per iteration at 7 000 silhouette rays, but 9.27 vs
+        9.14 at 12 544, 26.98 vs 26.85 at 224^2, 121.8 vs 122.1 at 512^2 (profiles/r04_ab_kernels.txt)."""
+        if (self.device.type != "cuda" or os.environ.get("AVC_PREFETCH_VIEW", "0") != "1" or os.environ.get("AVC_OVERLAP_HEAD", "1") == "0"
+                or getattr(self, "_view_future", None) is not None):
             return
-        if getattr(self, "_view_pool", None) is None:
-            from concurrent.futures import ThreadPoolExecutor
-            self._view_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="avc-view")
         camera = self.sample_camera(iter_i)
-        self._view_future = (iter_i, self._view_pool.submit(self._make_view_side, iter_i, camera, False))
+        if self.use_silhouettes:
+            if getattr(self, "_view_pool", None) is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._view_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="avc-view")
+            self._view_future = (iter_i, self._view_pool.submit(self._make_view_side, iter_i, camera, False, after))
+        else:
+            self._view_future = (iter_i, _Done(self._make_view_side(iter_i, camera, False, after)))
 
-    def _make_view_side(self, iter_i, camera, adopt=True):
+    def _make_view_side(self, iter_i, camera, adopt=True, after=None):
         main = torch.cuda.current_stream(self.device)
         side = getattr(self, "_side_stream", None)
         if side is None:
             side = self._side_stream = torch.cuda.Stream(device=self.device)
             side.wait_stream(main)       # first use: whatever initialisation is still in flight on the main stream
+        if after is not None:
+            side.wait_event(after)
         with torch.cuda.device(self.device), torch.cuda.stream(side):
             view = self.make_view(iter_i, camera)
             view.ready = torch.cuda.Event()
@@ -586,11 +594,16 @@ class Runner:
 
     def clip_loss(self, iter_i, camera=None):
         """main.py:348-534: one view from camera to scalar loss (differentiable)."""
-        view = self.make_view_on_side_stream(iter_i, camera) if self.use_silhouettes else self.make_view(iter_i, camera)
+        view = self._take_view(iter_i, camera)
         choice_i, background_rgb, masked_background_rgb = self.draw_background(view)
         render_out = self.renderer.render(view.rays_o, view.rays_d, view.near, view.far, background_rgb=masked_background_rgb,
                                           cos_anneal_ratio=self.get_cos_anneal_ratio())
         comp = self.shade_and_scatter(render_out, view, choice_i, background_rgb)
+        if camera is None and self.device.type == "cuda":
+            # every host draw of this iteration is made: the next view is prepared beside the CLIP pass that follows
+            reached = torch.cuda.Event()
+            reached.record(torch.cuda.current_stream(self.device))
+            self.prefetch_view(iter_i + 1, after=reached)
         loss, parts = self.assemble_loss(render_out, comp, view, iter_i)
         self.last_view = view
         return loss, parts
@@ -843,6 +856,16 @@ class Runner:
         mesh.write_ply(path, vertices, triangles, colors)
         logging.info("mesh: %d vertices, %d triangles -> %s", vertices.shape[0], triangles.shape[0], path)
         return path
+
+
+class _Done:
+    """a finished future (the full-frame view needs no helper thread: no round trips to wait for)"""
+
+    def __init__(self, value):
+        self._v = value
+
+    def result(self):
+        return self._v
 
 
 def clip_vit_random_state_dict(seed):

@@ -208,7 +208,6 @@ def timed_steps(runner, steps, warmup, dev, sync_debug=False):
     def step(i):
         runner.train_clip_iteration(i)
         runner.update_learning_rate()
-        runner.prefetch_view(i + 1)       # (silhouette mode only: the next view is prepared under this iteration's launches, as in Runner.train_clip)
 
     for i in range(warmup):
         step(i)

@@ -14,18 +14,18 @@ torch.manual_seed(0); np.random.seed(0)
 r = Runner(None, mode="train_clip", conf=conf, device=torch.device("cuda"))
 r.init_clip(); r.init_smpl(); r.update_learning_rate()
 for i in range(10):
-    r.train_clip_iteration(i); r.update_learning_rate(); r.prefetch_view(i + 1)
+    r.train_clip_iteration(i); r.update_learning_rate()
 torch.cuda.synchronize()
 N = 60
 t0 = time.time()
 for i in range(10, 10 + N):
-    r.train_clip_iteration(i); r.update_learning_rate(); r.prefetch_view(i + 1)
+    r.train_clip_iteration(i); r.update_learning_rate()
 torch.cuda.synchronize()
 print("unprofiled: %.2f ms per iteration" % ((time.time() - t0) / N * 1e3))
 pr = cProfile.Profile()
 pr.enable()
 for i in range(100, 100 + N):
-    r.train_clip_iteration(i); r.update_learning_rate(); r.prefetch_view(i + 1)
+    r.train_clip_iteration(i); r.update_learning_rate()
 torch.cuda.synchronize()
 pr.disable()
 for key, n in (("cumulative", 45), ("tottime", 35)):

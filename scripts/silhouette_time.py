@@ -18,10 +18,10 @@ torch.manual_seed(0); np.random.seed(0)
 r = Runner(None, mode="train_clip", conf=conf, device=torch.device("cuda"))
 r.init_clip(); r.init_smpl(); r.update_learning_rate()
 for i in range(8):
-    r.train_clip_iteration(i); r.update_learning_rate(); r.prefetch_view(i + 1)
+    r.train_clip_iteration(i); r.update_learning_rate()
 torch.cuda.synchronize(); t0 = time.time(); rays = 0
 for i in range(8, 8 + iters):
-    r.train_clip_iteration(i); r.update_learning_rate(); r.prefetch_view(i + 1); rays += int(r.last_stats["rays"])
+    r.train_clip_iteration(i); r.update_learning_rate(); rays += int(r.last_stats["rays"])
 torch.cuda.synchronize(); dt = (time.time() - t0) / iters
 print("silhouette mode: max_ray_num %d, dataset %dx%d, 64 spp, full nets: %.2f ms per iteration, %.0f rays per iteration on average, %.0f rays/s"
       % (max_rays, H, H, dt * 1e3, rays / iters, rays / iters / dt))

@@ -293,17 +293,18 @@ def test_train_clip_iteration_with_silhouette_rays_and_background_augmentation()
 
 
 @gpu
-def test_prefetched_views_keep_the_draw_order_and_the_losses(monkeypatch):
-    """Runner.prefetch_view (the next iteration's silhouette view prepared on a helper thread + side stream while this iteration is
-    being launched): same cameras, same ray sets, same background choices and the same losses as the run that prepares every view at
-    the start of its own iteration -- the numpy draw order of main.py:348-440 is untouched."""
+@pytest.mark.parametrize("silhouettes", [True, False])
+def test_prefetched_views_keep_the_draw_order_and_the_losses(monkeypatch, silhouettes):
+    """Runner.prefetch_view (the next iteration's view prepared on the side stream beside this iteration's CLIP pass; in silhouette
+    mode a helper thread makes its two round trips): same cameras, same ray sets, same background choices and the same losses as the
+    run that prepares every view at the start of its own iteration -- the numpy draw order of main.py:348-440 is untouched."""
     import bench
     from avatarclip_amd.runner import Runner
 
     def run(prefetch):
         monkeypatch.setenv("AVC_PREFETCH_VIEW", "1" if prefetch else "0")
-        conf = bench.make_conf(256, 32, small=True)
-        conf.put("train.use_silhouettes", True)
+        conf = bench.make_conf(256 if silhouettes else 48, 32, small=True)
+        conf.put("train.use_silhouettes", silhouettes)
         conf.put("train.max_ray_num", 3000)
         conf.put("train.warm_up_end", 0)
         torch.manual_seed(0)
@@ -317,8 +318,7 @@ def test_prefetched_views_keep_the_draw_order_and_the_losses(monkeypatch):
             loss = r.train_clip_iteration(i)
             rec.append((np.asarray(r.last_view.eye).copy(), int(r.last_stats["rays"]), float(loss)))
             r.update_learning_rate()
-            r.prefetch_view(i + 1)
-        assert (getattr(r, "_view_future", None) is not None) == prefetch      # (opt-in: AVC_PREFETCH_VIEW=1)
+        assert (getattr(r, "_view_future", None) is not None) == prefetch
         return rec
     a, b = run(True), run(False)
     for (e1, n1, l1), (e2, n2, l2) in zip(a, b):

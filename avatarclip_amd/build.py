@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, os.environ.get("AVC_LIB_NAME", "libavc.so"))
-SOURCES = ["avc_core.hip", "avc_mlp_fwd.hip", "avc_mlp_bwd.hip", "avc_bwd_ring.hip", "avc_wgrad.hip", "avc_rays.hip", "avc_vit.hip", "avc_vit_attn.hip", "avc_vit_gemm.hip", "avc_mcubes.hip", "avc_raster.hip", "avc_params.hip"]
+SOURCES = ["avc_core.hip", "avc_mlp_fwd.hip", "avc_mlp_bwd.hip", "avc_bwd_ring.hip", "avc_wgrad.hip", "avc_rays.hip", "avc_vit.hip", "avc_vit_attn.hip", "avc_vit_gemm.hip", "avc_mcubes.hip", "avc_raster.hip", "avc_params.hip", "avc_glue.hip"]
 HEADERS = ["avc_common.h", "avc_stage.h", "avc_mlp.h", "avc_bwd_body.h", "avc_wgrad_body.h", "avc_offsets_gen.h", os.path.join("..", "..", "include", "avc.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"] + os.environ.get("AVC_EXTRA_FLAGS", "").split()
 

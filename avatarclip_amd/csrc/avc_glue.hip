@@ -1,0 +1,295 @@
+// The per-pixel glue of one train_clip iteration between the renderer and CLIP, fused (AvatarGen/AppearanceGen/main.py:426-534):
+//   avc_shade_loss_fwd / _bwd   random-light Lambert shading of the rendered normals (main.py:426-453), the scatter of the silhouette
+//                               rays back into full images over the augmentation background (:461-487), and the per-pixel terms of the
+//                               colour L1 (:491-492) and mask BCE (:497) losses -- ~85 small torch launches forward and ~100 backward
+//                               become one kernel each way.
+//   avc_resize_norm_fwd / _bwd  CLIP's preprocessing of the two images (:510-511,516-517): bilinear resize to 224 x 224 (F.interpolate,
+//                               align_corners = False, no antialias) + Normalize, [B,H,W,3] -> [B,3,224,224].
+// fp32 throughout; the formulas are the reference's line by line (tests/test_gpu_glue.py compares values and gradients with the torch
+// statement of the same lines, Runner.shade_and_scatter / assemble_loss, which tests/test_glue_golden.py pins against the reference).
+// One thread per pixel of the (small) image; HBM / latency work, no matrix core.
+#include "avc_common.h"
+#include "../../include/avc.h"
+
+#define GLUE_THREADS 256
+
+struct GlueIn {
+  const float* color;      // [R,3] color_fine
+  const float* extra;      // [R,3] extra_color_fine
+  const float* wsum;       // [R]   weight_sum
+  const float* nsum;       // [R,3] sum_i w_i n_i (main.py:428 before its normalisation); NULL: no shading
+  const float* true_rgb;   // [P,3]
+  const float* mask;       // [P]   (already thresholded / all ones: what the losses use)
+  const int* ray_of_pixel; // [P] ray index of a pixel or -1; NULL: pixel p = ray p (full-frame mode)
+  const float* bg;         // [P] grey background of the CLIP images outside the silhouette, or NULL: bg_const
+  const float* light;      // device [4]: unit light direction, ambience
+  float bg_const;
+  int P;
+  int img0_is_extra;       // image 0 = extra_color (texture_cast_light off) instead of texture_shading
+};
+
+// per pixel: everything the forward produces, recomputed in the backward (a dozen flops)
+struct Shade {
+  float tex[3], rsh[3];   // texture_shading, rand_shading_rgb
+  float s, sp;            // rand_shading before / after the background rule
+  float dot, rho;         // n^ . l^ (before the clamp), |N|
+  bool bgm, dnan;
+};
+__device__ __forceinline__ Shade shade_pixel(const GlueIn& g, int r) {
+  Shade o;
+  const float E[3] = {g.extra[3 * r], g.extra[3 * r + 1], g.extra[3 * r + 2]};
+  if (!g.nsum) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { o.tex[c] = E[c]; o.rsh[c] = E[c]; }
+    o.s = o.sp = 1.f; o.dot = 0.f; o.rho = 0.f; o.bgm = true; o.dnan = false;
+    return o;
+  }
+  const float N[3] = {g.nsum[3 * r], g.nsum[3 * r + 1], g.nsum[3 * r + 2]};
+  o.rho = sqrtf(N[0] * N[0] + N[1] * N[1] + N[2] * N[2]);
+  const float inv = 1.f / (o.rho + 1e-7f);
+  o.dot = (N[0] * inv) * g.light[0] + (N[1] * inv) * g.light[1] + (N[2] * inv) * g.light[2];
+  float d = fminf(fmaxf(o.dot, 0.f), 1.f);
+  o.dnan = isnan(o.dot);
+  if (o.dnan) d = 1.f;                                   // main.py:437 (nan -> 1)
+  const float a = g.light[3];
+  o.s = a + (1.f - a) * d;
+  o.bgm = g.wsum[r] < 0.5f;                              // main.py:444
+  o.sp = o.bgm ? 1.f : o.s;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    o.rsh[c] = o.bgm ? E[c] : o.s;
+    o.tex[c] = fminf(fmaxf(E[c] * o.sp, 0.f), 1.f);
+  }
+  return o;
+}
+
+// images [2][P][3]: 0 = texture_shading (or extra_color when there is no shading), 1 = rand_shading_rgb;
+// partial [gridDim.x][4] = per-block sums of (|color - true| mask, mask, BCE term, 0)
+__global__ __launch_bounds__(GLUE_THREADS) void shade_loss_fwd_kernel(GlueIn g, float* __restrict__ images, float* __restrict__ partial) {
+  const int p = blockIdx.x * GLUE_THREADS + threadIdx.x;
+  float l1 = 0.f, ms = 0.f, bce = 0.f;
+  if (p < g.P) {
+    const int r = g.ray_of_pixel ? g.ray_of_pixel[p] : p;
+    float C[3] = {0.f, 0.f, 0.f}, ws = 0.f;
+    float i0[3], i1[3];
+    if (r >= 0) {
+      const Shade s = shade_pixel(g, r);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { C[c] = g.color[3 * r + c]; i0[c] = g.img0_is_extra ? g.extra[3 * r + c] : s.tex[c]; i1[c] = s.rsh[c]; }
+      ws = g.wsum[r];
+    } else {
+      const float b = g.bg ? g.bg[p] : g.bg_const;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { i0[c] = b; i1[c] = b; }
+    }
+    const float m = g.mask[p];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      images[(long)p * 3 + c] = i0[c];
+      images[((long)g.P + p) * 3 + c] = i1[c];
+      l1 += fabsf((C[c] - g.true_rgb[3 * p + c]) * m);
+    }
+    ms = m;
+    const float x = fminf(fmaxf(ws, 1e-3f), 1.f - 1e-3f);
+    bce = -(m * fmaxf(logf(x), -100.f) + (1.f - m) * fmaxf(logf(1.f - x), -100.f));   // F.binary_cross_entropy (log clamped at -100)
+  }
+  __shared__ float red[3][GLUE_THREADS / 64];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { l1 += __shfl_xor(l1, d); ms += __shfl_xor(ms, d); bce += __shfl_xor(bce, d); }
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wv] = l1; red[1][wv] = ms; red[2][wv] = bce; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int w = 0; w < GLUE_THREADS / 64; ++w) { a += red[0][w]; b += red[1][w]; c += red[2][w]; }
+    partial[4 * blockIdx.x + 0] = a; partial[4 * blockIdx.x + 1] = b; partial[4 * blockIdx.x + 2] = c; partial[4 * blockIdx.x + 3] = 0.f;
+  }
+}
+
+// gs (device [2]) = d loss / d (l1 sum), d loss / d (bce sum); dimages [2][P][3] (either half may be NULL: that image is not used)
+__global__ __launch_bounds__(GLUE_THREADS) void shade_loss_bwd_kernel(GlueIn g, const float* __restrict__ dimg0, const float* __restrict__ dimg1,
+                                                                      const float* __restrict__ gs, float* __restrict__ dcolor,
+                                                                      float* __restrict__ dextra, float* __restrict__ dwsum, float* __restrict__ dnsum) {
+  const int p = blockIdx.x * GLUE_THREADS + threadIdx.x;
+  if (p >= g.P) return;
+  const int r = g.ray_of_pixel ? g.ray_of_pixel[p] : p;
+  if (r < 0) return;
+  const float m = g.mask[p], gl1 = gs[0], gbce = gs[1];
+  // colour L1: d |e| = sign(e), e = (C - T) m
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float e = (g.color[3 * r + c] - g.true_rgb[3 * p + c]) * m;
+    dcolor[3 * r + c] = gl1 * m * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
+  }
+  // mask BCE through the clip (gradient passes inside [1e-3, 1 - 1e-3], ends included)
+  const float ws = g.wsum[r];
+  float dws = 0.f;
+  if (ws >= 1e-3f && ws <= 1.f - 1e-3f) {
+    // (the -100 clamp of the logarithms is inactive inside the clip range)
+    dws = gbce * (-m / ws + (1.f - m) / (1.f - ws));
+  }
+  dwsum[r] = dws;
+  const Shade s = shade_pixel(g, r);
+  float dE[3] = {0.f, 0.f, 0.f}, ds = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float E = g.extra[3 * r + c];
+    const float g0 = dimg0 ? dimg0[(long)p * 3 + c] : 0.f, g1 = dimg1 ? dimg1[(long)p * 3 + c] : 0.f;
+    if (!g.nsum) { dE[c] = g0 + g1; continue; }
+    if (g.img0_is_extra) {
+      dE[c] += g0;
+    } else {
+      const float t = E * s.sp;
+      const float gt = (t >= 0.f && t <= 1.f) ? g0 : 0.f;   // clamp(min=0, max=1)
+      dE[c] += gt * s.sp;
+      if (!s.bgm) ds += gt * E;                              // s' = s on the body, the constant 1 on the background
+    }
+    if (s.bgm) dE[c] += g1; else ds += g1;                   // rand_shading_rgb = extra on the background, s (x3) on the body
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) dextra[3 * r + c] = dE[c];
+  if (g.nsum) {
+    float dN[3] = {0.f, 0.f, 0.f};
+    const float dd = (1.f - g.light[3]) * ds;
+    if (!s.dnan && s.dot >= 0.f && s.dot <= 1.f && dd != 0.f) {
+      // dot = n^ . l^, n^ = N / (rho + eps):  dN = dn^ / (rho + eps) - N (N . dn^) / (rho (rho + eps)^2), dn^ = dd l^
+      const float N[3] = {g.nsum[3 * r], g.nsum[3 * r + 1], g.nsum[3 * r + 2]};
+      const float re = s.rho + 1e-7f;
+      const float ndl = (N[0] * g.light[0] + N[1] * g.light[1] + N[2] * g.light[2]) * dd;
+      const float k = s.rho > 0.f ? ndl / (s.rho * re * re) : 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dN[c] = dd * g.light[c] / re - N[c] * k;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dnsum[3 * r + c] = dN[c];
+  }
+}
+
+extern "C" int avc_shade_loss_blocks(int P) { return (P + GLUE_THREADS - 1) / GLUE_THREADS; }
+
+static GlueIn glue_in(const float* color, const float* extra, const float* wsum, const float* nsum, const float* true_rgb, const float* mask,
+                      const int* ray_of_pixel, const float* bg, float bg_const, const float* light, int P, int img0_is_extra) {
+  GlueIn g;
+  g.color = color; g.extra = extra; g.wsum = wsum; g.nsum = nsum; g.true_rgb = true_rgb; g.mask = mask; g.ray_of_pixel = ray_of_pixel;
+  g.bg = bg; g.light = light; g.bg_const = bg_const; g.P = P; g.img0_is_extra = img0_is_extra;
+  return g;
+}
+
+extern "C" int avc_shade_loss_fwd(const float* color, const float* extra, const float* wsum, const float* nsum, const float* true_rgb,
+                                  const float* mask, const int* ray_of_pixel, const float* bg, float bg_const, const float* light, int P,
+                                  int img0_is_extra, float* images, float* partial, void* stream) {
+  if (P <= 0) return 0;
+  if (!color || !extra || !wsum || !true_rgb || !mask || !images || !partial || (nsum && !light)) { avc_set_error("avc_shade_loss_fwd: NULL buffer"); return 1; }
+  hipLaunchKernelGGL(shade_loss_fwd_kernel, dim3(avc_shade_loss_blocks(P)), dim3(GLUE_THREADS), 0, (hipStream_t)stream,
+                     glue_in(color, extra, wsum, nsum, true_rgb, mask, ray_of_pixel, bg, bg_const, light, P, img0_is_extra), images, partial);
+  return avc_check_launch("avc_shade_loss_fwd");
+}
+
+extern "C" int avc_shade_loss_bwd(const float* color, const float* extra, const float* wsum, const float* nsum, const float* true_rgb,
+                                  const float* mask, const int* ray_of_pixel, const float* light, int P, int img0_is_extra,
+                                  const float* dimg0, const float* dimg1, const float* gs, float* dcolor, float* dextra, float* dwsum,
+                                  float* dnsum, void* stream) {
+  if (P <= 0) return 0;
+  if (!color || !extra || !wsum || !true_rgb || !mask || !gs || !dcolor || !dextra || !dwsum || (nsum && (!light || !dnsum))) {
+    avc_set_error("avc_shade_loss_bwd: NULL buffer");
+    return 1;
+  }
+  hipLaunchKernelGGL(shade_loss_bwd_kernel, dim3(avc_shade_loss_blocks(P)), dim3(GLUE_THREADS), 0, (hipStream_t)stream,
+                     glue_in(color, extra, wsum, nsum, true_rgb, mask, ray_of_pixel, nullptr, 0.f, light, P, img0_is_extra), dimg0, dimg1, gs,
+                     dcolor, dextra, dwsum, dnsum);
+  return avc_check_launch("avc_shade_loss_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// F.interpolate(mode='bilinear', align_corners=False) source coordinates: src = scale (dst + 0.5) - 0.5, clamped at 0
+struct Lerp { int i0, i1; float w0, w1; };
+__device__ __forceinline__ Lerp lerp_of(int dst, int in_size, float scale) {
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  Lerp l;
+  l.i0 = (int)src;
+  if (l.i0 > in_size - 1) l.i0 = in_size - 1;
+  l.i1 = l.i0 + (l.i0 < in_size - 1 ? 1 : 0);
+  l.w1 = src - (float)l.i0;
+  l.w0 = 1.f - l.w1;
+  return l;
+}
+#define CLIP_RES 224
+struct Norm3 { float mean[3], istd[3]; };
+
+// in [B,H,W,3] -> out [B,3,224,224] = (resize(in) - mean) / std
+__global__ __launch_bounds__(GLUE_THREADS) void resize_norm_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W,
+                                                                       Norm3 nm) {
+  const int idx = blockIdx.x * GLUE_THREADS + threadIdx.x;
+  if (idx >= B * CLIP_RES * CLIP_RES) return;
+  const int x = idx % CLIP_RES, y = (idx / CLIP_RES) % CLIP_RES, b = idx / (CLIP_RES * CLIP_RES);
+  const float* ib = in + (long)b * H * W * 3;
+  float v[3];
+  if (H == CLIP_RES && W == CLIP_RES) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = ib[((long)y * W + x) * 3 + c];
+  } else {
+    const Lerp ly = lerp_of(y, H, (float)H / CLIP_RES), lx = lerp_of(x, W, (float)W / CLIP_RES);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float a = ib[((long)ly.i0 * W + lx.i0) * 3 + c], bb = ib[((long)ly.i0 * W + lx.i1) * 3 + c];
+      const float cc = ib[((long)ly.i1 * W + lx.i0) * 3 + c], d = ib[((long)ly.i1 * W + lx.i1) * 3 + c];
+      v[c] = ly.w0 * (lx.w0 * a + lx.w1 * bb) + ly.w1 * (lx.w0 * cc + lx.w1 * d);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) out[(((long)b * 3 + c) * CLIP_RES + y) * CLIP_RES + x] = (v[c] - nm.mean[c]) * nm.istd[c];
+}
+// din [B,H,W,3] (zeroed by the launcher) += the transpose of the map above applied to dout [B,3,224,224]
+__global__ __launch_bounds__(GLUE_THREADS) void resize_norm_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int B, int H, int W,
+                                                                       Norm3 nm) {
+  const int idx = blockIdx.x * GLUE_THREADS + threadIdx.x;
+  if (idx >= B * CLIP_RES * CLIP_RES) return;
+  const int x = idx % CLIP_RES, y = (idx / CLIP_RES) % CLIP_RES, b = idx / (CLIP_RES * CLIP_RES);
+  float* ib = din + (long)b * H * W * 3;
+  float gv[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) gv[c] = dout[(((long)b * 3 + c) * CLIP_RES + y) * CLIP_RES + x] * nm.istd[c];
+  if (H == CLIP_RES && W == CLIP_RES) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ib[((long)y * W + x) * 3 + c] = gv[c];
+    return;
+  }
+  const Lerp ly = lerp_of(y, H, (float)H / CLIP_RES), lx = lerp_of(x, W, (float)W / CLIP_RES);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    atomicAdd(&ib[((long)ly.i0 * W + lx.i0) * 3 + c], ly.w0 * lx.w0 * gv[c]);
+    atomicAdd(&ib[((long)ly.i0 * W + lx.i1) * 3 + c], ly.w0 * lx.w1 * gv[c]);
+    atomicAdd(&ib[((long)ly.i1 * W + lx.i0) * 3 + c], ly.w1 * lx.w0 * gv[c]);
+    atomicAdd(&ib[((long)ly.i1 * W + lx.i1) * 3 + c], ly.w1 * lx.w1 * gv[c]);
+  }
+}
+
+static Norm3 norm3(const float* mean, const float* stdv) {
+  Norm3 n;
+  for (int c = 0; c < 3; ++c) { n.mean[c] = mean[c]; n.istd[c] = 1.f / stdv[c]; }
+  return n;
+}
+extern "C" int avc_resize_norm_fwd(const float* images, int B, int H, int W, const float* mean /* host [3] */, const float* stdv /* host [3] */,
+                                   float* out, void* stream) {
+  if (B <= 0) return 0;
+  if (!images || !out || !mean || !stdv || H < 1 || W < 1) { avc_set_error("avc_resize_norm_fwd: bad arguments"); return 1; }
+  const int n = B * CLIP_RES * CLIP_RES;
+  hipLaunchKernelGGL(resize_norm_fwd_kernel, dim3((n + GLUE_THREADS - 1) / GLUE_THREADS), dim3(GLUE_THREADS), 0, (hipStream_t)stream, images, out, B,
+                     H, W, norm3(mean, stdv));
+  return avc_check_launch("avc_resize_norm_fwd");
+}
+extern "C" int avc_resize_norm_bwd(const float* dout, int B, int H, int W, const float* mean /* host [3] */, const float* stdv /* host [3] */,
+                                   float* dimages, void* stream) {
+  if (B <= 0) return 0;
+  if (!dout || !dimages || !mean || !stdv || H < 1 || W < 1) { avc_set_error("avc_resize_norm_bwd: bad arguments"); return 1; }
+  if (!(H == CLIP_RES && W == CLIP_RES) &&
+      hipMemsetAsync(dimages, 0, (size_t)B * H * W * 3 * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+    avc_set_error("avc_resize_norm_bwd: memset failed");
+    return 1;
+  }
+  const int n = B * CLIP_RES * CLIP_RES;
+  hipLaunchKernelGGL(resize_norm_bwd_kernel, dim3((n + GLUE_THREADS - 1) / GLUE_THREADS), dim3(GLUE_THREADS), 0, (hipStream_t)stream, dout, dimages,
+                     B, H, W, norm3(mean, stdv));
+  return avc_check_launch("avc_resize_norm_bwd");
+}

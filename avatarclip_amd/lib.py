@@ -43,6 +43,11 @@ _SIGS = {
     "avc_dense_params_fwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P]),
     "avc_dense_params_bwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P]),
     "avc_weight_grad_all": (c_int, [P, c_int, P, c_int, c_int, P, c_long, P, P, c_int, c_int, c_int, P]),
+    "avc_shade_loss_blocks": (c_int, [c_int]),
+    "avc_shade_loss_fwd": (c_int, [P, P, P, P, P, P, P, P, c_float, P, c_int, c_int, P, P, P]),
+    "avc_shade_loss_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P, P, P, P, P]),
+    "avc_resize_norm_fwd": (c_int, [P, c_int, c_int, c_int, P, P, P, P]),
+    "avc_resize_norm_bwd": (c_int, [P, c_int, c_int, c_int, P, P, P, P]),
     "avc_bwd_ring_ctl_bytes": (c_long, []),
     "avc_bwd_ring_payload_bytes": (c_long, [c_int, c_int, c_int]),
     "avc_bwd_ring_types": (c_int, [c_int]),

@@ -400,9 +400,13 @@ class Runner:
             .squeeze(0).permute(1, 2, 0).reshape(-1, 3)                                        # main.py:376-377 (nearest)
         mask = (true_rgb != 0).float()[..., :1]
         near, far = self.dataset.near_far_from_sphere(rays_o, rays_d)
+        ray_of_pixel = None
+        if sel_idx is not None and dev.type == "cuda":     # pixel -> ray (or -1): what the fused glue scatters with (glue.ShadeLossFn)
+            ray_of_pixel = torch.full((H * W,), -1, dtype=torch.int32, device=dev)
+            ray_of_pixel[sel_idx] = torch.arange(sel_idx.numel(), dtype=torch.int32, device=dev)
         return types.SimpleNamespace(eye=eye, at=at, theta=theta, phi=phi, is_front=is_front, pose=pose, H=H, W=W,
                                      rays_o=rays_o, rays_d=rays_d, near=near, far=far, true_rgb=true_rgb, mask=mask,
-                                     dilated_mask=dilated_mask, sel_idx=sel_idx)
+                                     dilated_mask=dilated_mask, sel_idx=sel_idx, ray_of_pixel=ray_of_pixel)
 
     def _take_view(self, iter_i, camera=None):
         """the view of this iteration: the one prefetch_view prepared, or a fresh one (silhouette mode: on the side stream)"""
@@ -592,19 +596,87 @@ class Runner:
         return loss, dict(color=color_fine_loss, eikonal=eikonal_loss, mask=mask_loss, cosine=cosine, cosine_shading=cosine_shading,
                           psnr=psnr, s_val=render_out["s_val"][:1].mean())
 
+    def fused_shade_loss(self, render_out, view, choice_i, background_rgb, iter_i, light=None):
+        """shade_and_scatter + assemble_loss (main.py:422-534) through the two fused kernels of glue.py: same host draws in the same
+        order (light direction, ambience), same images into CLIP, same loss terms -- ~150 small launches fewer per iteration
+        (tests/test_gpu_glue.py: values and gradients against the torch statement).  AVC_FUSED_GLUE=0: the torch statement."""
+        from . import glue
+        dev, H, W = self.device, view.H, view.W
+        P = H * W
+        shading = self.add_no_texture or self.texture_cast_light
+        light4 = nsum = None
+        if shading:
+            if light is None:
+                light_dir = sphere_coord(view.theta + np.random.uniform(-np.pi / 4, np.pi / 4),
+                                         view.phi + np.random.uniform(-np.pi / 4, np.pi / 4))
+                ambience = np.random.uniform(0, 0.2)
+            else:
+                light_dir, ambience = np.asarray(light[0]), float(light[1])
+            light4 = h2d.upload(glue.unit_light(light_dir, ambience), dev)
+            nsum = getattr(render_out, "weighted_normals", None)
+            if nsum is None:
+                nsum = (render_out["gradients"] * render_out["weights"][:, :, None]).sum(dim=1)
+        bg, bg_const, rop = None, 0.0, None
+        if self.use_silhouettes:
+            rop = view.ray_of_pixel
+            if choice_i == 0:
+                bg_const = 1.0
+            elif choice_i in (1, 2):
+                bg = background_rgb.reshape(-1)
+        mask = (view.mask > 0.5).float() if self.mask_weight > 0.0 else torch.ones_like(view.mask)
+        images, l1, mask_sum, bce, sq = glue.ShadeLossFn.apply(
+            render_out["color_fine"], render_out["extra_color_fine"], render_out["weight_sum"].reshape(-1), nsum, view.true_rgb,
+            mask.reshape(-1), rop, bg, bg_const, light4, not self.texture_cast_light)
+        mask_sum = mask_sum + 1e-5
+        color_fine_loss = l1 / mask_sum
+        mask_loss = bce / P
+        psnr = None
+        if self.writer is not None:   # main.py:493 (a logged statistic only)
+            with torch.no_grad():
+                psnr = 20.0 * torch.log10(1.0 / (sq / (mask_sum * 3.0)).sqrt())
+        eikonal_loss = render_out["gradient_error"]
+        if self.use_face_prompt and iter_i % 4 == 0:
+            text = self.encoded_face_text
+        elif self.use_back_prompt and view.is_front == 0:
+            text = self.encoded_back_text
+        else:
+            text = self.encoded_text
+        B = 2 if self.add_no_texture else 1
+        enc_both = self.perceptor.encode_image(glue.ResizeNormFn.apply(images[:B].reshape(B, H, W, 3)))
+        cosine = torch.cosine_similarity(torch.mean(enc_both[0:1], dim=0), torch.mean(text, dim=0), dim=0)
+        loss = color_fine_loss + eikonal_loss * self.igr_weight + mask_loss * self.mask_weight + (1.0 - cosine) * self.clip_weight
+        cosine_shading = None
+        if self.add_no_texture:
+            cosine_shading = torch.cosine_similarity(torch.mean(enc_both[1:2], dim=0), torch.mean(text, dim=0), dim=0)
+            loss = loss + (1.0 - cosine_shading) * self.clip_weight
+        return loss, dict(color=color_fine_loss, eikonal=eikonal_loss, mask=mask_loss, cosine=cosine, cosine_shading=cosine_shading,
+                          psnr=psnr, s_val=render_out["s_val"][:1].mean()), images
+
     def clip_loss(self, iter_i, camera=None):
         """main.py:348-534: one view from camera to scalar loss (differentiable)."""
         view = self._take_view(iter_i, camera)
         choice_i, background_rgb, masked_background_rgb = self.draw_background(view)
         render_out = self.renderer.render(view.rays_o, view.rays_d, view.near, view.far, background_rgb=masked_background_rgb,
                                           cos_anneal_ratio=self.get_cos_anneal_ratio())
-        comp = self.shade_and_scatter(render_out, view, choice_i, background_rgb)
+        fused = (self.device.type == "cuda" and os.environ.get("AVC_FUSED_GLUE", "1") != "0"
+                 and not (self.use_silhouettes and getattr(view, "ray_of_pixel", None) is None))
+        if fused:
+            # (its host draws -- light direction, ambience -- come first, as in shade_and_scatter; the prefetch draws the next camera)
+            light = None
+            if self.add_no_texture or self.texture_cast_light:
+                light = (sphere_coord(view.theta + np.random.uniform(-np.pi / 4, np.pi / 4), view.phi + np.random.uniform(-np.pi / 4, np.pi / 4)),
+                         np.random.uniform(0, 0.2))
+        else:
+            comp = self.shade_and_scatter(render_out, view, choice_i, background_rgb)
         if camera is None and self.device.type == "cuda":
             # every host draw of this iteration is made: the next view is prepared beside the CLIP pass that follows
             reached = torch.cuda.Event()
             reached.record(torch.cuda.current_stream(self.device))
             self.prefetch_view(iter_i + 1, after=reached)
-        loss, parts = self.assemble_loss(render_out, comp, view, iter_i)
+        if fused:
+            loss, parts, _ = self.fused_shade_loss(render_out, view, choice_i, background_rgb, iter_i, light=light)
+        else:
+            loss, parts = self.assemble_loss(render_out, comp, view, iter_i)
         self.last_view = view
         return loss, parts
 

@@ -142,6 +142,28 @@ int avc_render_points_bwd_ring(int net, const float* pts, const float* rays_o, c
                                void* ring, float* partial, float* bias_partial, const int* pb_tiles /* host */, int ntypes,
                                int cpt, int nslots, int grid, void* stream);
 
+/* The per-pixel glue between the renderer and CLIP in one launch each way (main.py:426-453 random-light Lambert shading of the rendered
+ * normals, :461-487 scatter of the silhouette rays into full images over the augmentation background, :491-492 / :497 the per-pixel terms
+ * of the colour L1 and mask BCE losses).  P pixels of the H x W image; ray_of_pixel[P] = the ray of a pixel or -1 (NULL: pixel p = ray p,
+ * the full-frame mode); color / extra [R,3], wsum [R], nsum [R,3] = sum_i w_i n_i (NULL: no shading, both images = extra_color);
+ * true_rgb [P,3], mask [P] (what the losses use); bg [P] grey background outside the silhouette (NULL: bg_const); light = device
+ * [4] (unit light direction, ambience).  Outputs: images [2][P][3] (0 = texture_shading, or extra_color if img0_is_extra; 1 =
+ * rand_shading_rgb) and partial [avc_shade_loss_blocks(P)][4] = per-block sums of (|color - true| mask, mask, BCE term, 0), summed by the
+ * caller.  The backward takes dimg0 / dimg1 [P,3] (NULL: unused image) and gs = device [2] (d loss / d l1-sum, d loss / d bce-sum) and
+ * writes dcolor / dextra [R,3], dwsum [R], dnsum [R,3] for every ray that owns a pixel. */
+int avc_shade_loss_blocks(int P);
+int avc_shade_loss_fwd(const float* color, const float* extra, const float* wsum, const float* nsum, const float* true_rgb,
+                       const float* mask, const int* ray_of_pixel, const float* bg, float bg_const, const float* light, int P,
+                       int img0_is_extra, float* images, float* partial, void* stream);
+int avc_shade_loss_bwd(const float* color, const float* extra, const float* wsum, const float* nsum, const float* true_rgb,
+                       const float* mask, const int* ray_of_pixel, const float* light, int P, int img0_is_extra, const float* dimg0,
+                       const float* dimg1, const float* gs, float* dcolor, float* dextra, float* dwsum, float* dnsum, void* stream);
+/* CLIP's preprocessing (main.py:261-267,510-511: RandomResizedCrop(224, scale=(1,1)) of a square image = bilinear resize,
+ * align_corners = False, no antialias; Normalize): images [B,H,W,3] -> out [B,3,224,224] = (resize - mean) / std, and its transpose
+ * (dimages is overwritten).  mean / std: HOST arrays of 3 floats. */
+int avc_resize_norm_fwd(const float* images, int B, int H, int W, const float* mean, const float* stdv, float* out, void* stream);
+int avc_resize_norm_bwd(const float* dout, int B, int H, int W, const float* mean, const float* stdv, float* dimages, void* stream);
+
 /* Dense-parameter assembly of one optimisation step: W_l = g_l * v_l / ||v_l||_row (nn.utils.weight_norm, fields.py:65-66,139-143;
  * g[l] == NULL: the plain weight) and the biases of `n` linears written into the flat dense vector `flat` at w_off[l] (row-major
  * [rows, cols]) / b_off[l] (floats), and the backward of that map: dflat -> dv[l], dg[l], db[l] (b[l] / db[l] may be NULL).

@@ -1,0 +1,108 @@
+"""The fused glue kernels (csrc/avc_glue.hip, avatarclip_amd/glue.py: Lambert shading + silhouette scatter + per-pixel loss terms, and
+CLIP's resize + normalise) against the torch statement of the same reference lines (Runner.shade_and_scatter / assemble_loss = main.py:
+422-534, themselves pinned against the reference's own lines by tests/test_glue_golden.py): images, loss terms and the gradients with
+respect to everything the renderer hands over, for every flag combination and every background choice, in both sampling modes."""
+import numpy as np
+import pytest
+import torch
+
+gpu = pytest.mark.gpu
+
+
+class _StubPerceptor:
+    """a smooth fp32 stand-in for encode_image, so that the comparison tests the glue and not bf16 rounding flips inside the ViT"""
+
+    def __init__(self, dev):
+        g = torch.Generator().manual_seed(3)
+        self.w = (torch.randn(3 * 224 * 224, 512, generator=g) / 400.0).to(dev)
+
+    def encode_image(self, x):
+        return x.reshape(x.shape[0], -1) @ self.w
+
+
+def _runner(silhouettes, add_no_texture, texture_cast_light, dev):
+    import bench
+    from avatarclip_amd.runner import Runner
+    conf = bench.make_conf(256 if silhouettes else 56, 32, small=True)
+    conf.put("train.use_silhouettes", silhouettes)
+    conf.put("train.max_ray_num", 2500)
+    conf.put("train.add_no_texture", add_no_texture)
+    conf.put("train.texture_cast_light", texture_cast_light)
+    conf.put("train.warm_up_end", 0)
+    torch.manual_seed(0)
+    np.random.seed(5)
+    r = Runner(None, mode="train_clip", conf=conf, device=dev)
+    r.init_clip(perceptor=_StubPerceptor(dev))
+    r.init_smpl()
+    return r
+
+
+@gpu
+@pytest.mark.parametrize("silhouettes", [True, False])
+@pytest.mark.parametrize("add_no_texture,texture_cast_light", [(True, True), (True, False), (False, True), (False, False)])
+def test_fused_glue_equals_the_torch_statement(silhouettes, add_no_texture, texture_cast_light):
+    from avatarclip_amd.renderer import RenderOut
+    dev = torch.device("cuda")
+    r = _runner(silhouettes, add_no_texture, texture_cast_light, dev)
+    for it, choice in enumerate((0, 1, 2, 3) if silhouettes else (3,)):
+        view = r.make_view(it)
+        _, background_rgb, masked_bg = r.draw_background(view, choice_i=choice)
+        with torch.no_grad():
+            ro = r.renderer.render(view.rays_o, view.rays_d, view.near, view.far, background_rgb=masked_bg, cos_anneal_ratio=1.0)
+        R = view.rays_o.shape[0]
+        g = torch.Generator().manual_seed(11 + it)
+        base = dict(color_fine=ro["color_fine"], extra_color_fine=ro["extra_color_fine"] * 1.3 - 0.1,     # (some values outside [0,1]: the clamps)
+                    weight_sum=(ro["weight_sum"] + (torch.rand(R, 1, generator=g).to(dev) - 0.5) * 0.6).clamp(-0.05, 1.05),
+                    weighted_normals=ro.weighted_normals + torch.randn(R, 3, generator=g).to(dev) * 0.05)
+        light = (np.array([0.3, -0.5, 0.8]), 0.13)
+        res = []
+        for fused in (False, True):
+            leaf = {k: v.detach().clone().requires_grad_(True) for k, v in base.items()}
+            out = RenderOut({"color_fine": leaf["color_fine"], "extra_color_fine": leaf["extra_color_fine"], "weight_sum": leaf["weight_sum"],
+                             "gradient_error": ro["gradient_error"].detach(), "s_val": ro["s_val"]})
+            out.weighted_normals = leaf["weighted_normals"]
+            if fused:
+                loss, parts, images = r.fused_shade_loss(out, view, choice, background_rgb, it, light=light)
+            else:
+                comp = r.shade_and_scatter(out, view, choice, background_rgb, light=light)
+                loss, parts = r.assemble_loss(out, comp, view, it)
+                img0 = comp["texture_shading"] if texture_cast_light else comp["extra_color_fine"]
+                img1 = comp["rand_shading_rgb"] if comp["rand_shading_rgb"] is not None else img0
+                images = torch.stack([img0.reshape(-1, 3), img1.reshape(-1, 3)])
+            loss.backward()
+            res.append((loss.detach(), {k: v.detach() for k, v in parts.items() if v is not None and k in ("color", "mask", "cosine", "cosine_shading")},
+                        images.detach(), {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()}))
+        (la, pa, ia, ga), (lb, pb, ib, gb) = res
+        nimg = 2 if add_no_texture else 1
+        assert (ia[:nimg] - ib[:nimg]).abs().max() < 1e-6, (choice, (ia[:nimg] - ib[:nimg]).abs().max())
+        assert abs(la.item() - lb.item()) < 1e-5 * max(1.0, abs(la.item())), (choice, la.item(), lb.item())
+        for k in pa:
+            assert abs(pa[k].item() - pb[k].item()) < 1e-5 * max(1.0, abs(pa[k].item())), (choice, k, pa[k].item(), pb[k].item())
+        for k in ga:
+            if not (add_no_texture or texture_cast_light) and k == "weighted_normals":
+                assert ga[k].abs().max() == 0 and gb[k].abs().max() == 0
+                continue
+            den = ga[k].norm().item()
+            assert den > 0, k
+            rel = (ga[k] - gb[k]).norm().item() / den
+            assert rel < 2e-5, (choice, k, rel)
+
+
+@gpu
+@pytest.mark.parametrize("H", [224, 97, 300])
+def test_resize_norm_equals_interpolate(H):
+    from avatarclip_amd import glue
+    from avatarclip_amd.clip_vit import clip_preprocess
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(2)
+    img = torch.rand(2, H, H, 3, generator=g).to(dev)
+    a = img.clone().requires_grad_(True)
+    b = img.clone().requires_grad_(True)
+    ya = torch.cat([clip_preprocess(a[i]) for i in range(2)], dim=0)
+    yb = glue.ResizeNormFn.apply(b)
+    assert ya.shape == yb.shape == (2, 3, 224, 224)
+    assert (ya - yb).abs().max() < 2e-5
+    w = torch.randn(2, 3, 224, 224, generator=g).to(dev)
+    (ya * w).sum().backward()
+    (yb * w).sum().backward()
+    assert (a.grad - b.grad).abs().max() < 1e-4 * a.grad.abs().max()

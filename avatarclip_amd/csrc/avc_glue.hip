@@ -293,3 +293,97 @@ extern "C" int avc_resize_norm_bwd(const float* dout, int B, int H, int W, const
                      B, H, W, norm3(mean, stdv));
   return avc_check_launch("avc_resize_norm_bwd");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The head of an iteration: rays of a view (dataset.py:277-293 gen_rays_pose / :252-275 the selected pixels of gen_rays_silhouettes),
+// their near / far from the unit sphere (:331-342), and the prior image resampled to the ray grid (main.py:376-380: nearest) -- ~45 small
+// torch launches as one.  torch.linspace's own formula (start + i step below the middle, end - (n - 1 - i) step above) so that the
+// pixel centres are the same floats.
+__device__ __forceinline__ float linspace_at(float end, int n, int i) {   // torch.linspace(0, end, n)[i], float32
+  if (n == 1) return 0.f;
+  const float step = end / (float)(n - 1);
+  return i < n / 2 ? step * (float)i : end - step * (float)(n - 1 - i);
+}
+struct RaysIn {
+  const float* pose;        // device [16]: camera-to-world 4 x 4, row major
+  const long* sel;          // [R] row-major pixel of ray r in the Hn x Wn grid, or NULL: ray r = pixel r
+  const float* prior;       // [Hp, Wp, 3] prior render (0 = background), or NULL
+  float W, H, focal;        // the dataset's pinhole camera
+  int Wn, Hn, R, Hp, Wp;
+};
+__global__ __launch_bounds__(GLUE_THREADS) void gen_rays_kernel(RaysIn a, float* __restrict__ rays_o, float* __restrict__ rays_d,
+                                                                float* __restrict__ near, float* __restrict__ far,
+                                                                float* __restrict__ true_rgb, float* __restrict__ mask) {
+#pragma clang fp contract(off)   // every float32 operation rounds like the torch op it replaces (a fused multiply-add would move a ray by an ulp)
+  const int t = blockIdx.x * GLUE_THREADS + threadIdx.x;
+  if (t < a.R) {
+    const long p = a.sel ? a.sel[t] : (long)t;
+    const int iy = (int)(p / a.Wn), ix = (int)(p % a.Wn);
+    const float px = linspace_at(a.W - 1.f, a.Wn, ix), py = linspace_at(a.H - 1.f, a.Hn, iy);
+    const float c0 = (px - 0.5f * a.W) / a.focal, c1 = -(py - 0.5f * a.H) / a.focal, c2 = -1.f;
+    const float nrm = sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
+    const float v0 = c0 / nrm, v1 = c1 / nrm, v2 = c2 / nrm;
+    float d[3], o[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      d[i] = v0 * a.pose[4 * i] + v1 * a.pose[4 * i + 1] + v2 * a.pose[4 * i + 2];
+      o[i] = a.pose[4 * i + 3];
+      rays_d[3 * t + i] = d[i];
+      rays_o[3 * t + i] = o[i];
+    }
+    const float aa = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    const float bb = 2.f * (o[0] * d[0] + o[1] * d[1] + o[2] * d[2]);
+    const float mid = 0.5f * (-bb) / aa;
+    near[t] = fmaxf(mid - 1.f, 0.f);
+    far[t] = mid + 1.f;
+  }
+  if (a.prior && t < a.Wn * a.Hn) {     // F.interpolate(mode='nearest'): source index floor(dst * in / out)
+    const int iy = t / a.Wn, ix = t % a.Wn;
+    int sy = (int)floorf((float)iy * ((float)a.Hp / (float)a.Hn)), sx = (int)floorf((float)ix * ((float)a.Wp / (float)a.Wn));
+    if (sy > a.Hp - 1) sy = a.Hp - 1;
+    if (sx > a.Wp - 1) sx = a.Wp - 1;
+    const float* s = a.prior + ((long)sy * a.Wp + sx) * 3;
+    true_rgb[3 * t] = s[0]; true_rgb[3 * t + 1] = s[1]; true_rgb[3 * t + 2] = s[2];
+    mask[t] = s[0] != 0.f ? 1.f : 0.f;                 // main.py:379-380: mask = (true_rgb != 0)[..., :1]
+  }
+}
+extern "C" int avc_gen_rays(const float* pose, const long* sel, const float* prior, int Hp, int Wp, float W, float H, float focal, int Wn, int Hn,
+                            int R, float* rays_o, float* rays_d, float* near, float* far, float* true_rgb, float* mask, void* stream) {
+  if (R <= 0 && !prior) return 0;
+  if (!pose || (R > 0 && (!rays_o || !rays_d || !near || !far)) || (prior && (!true_rgb || !mask))) { avc_set_error("avc_gen_rays: NULL buffer"); return 1; }
+  RaysIn a;
+  a.pose = pose; a.sel = sel; a.prior = prior; a.W = W; a.H = H; a.focal = focal; a.Wn = Wn; a.Hn = Hn; a.R = R; a.Hp = Hp; a.Wp = Wp;
+  const int n = prior ? (R > Wn * Hn ? R : Wn * Hn) : R;
+  hipLaunchKernelGGL(gen_rays_kernel, dim3((n + GLUE_THREADS - 1) / GLUE_THREADS), dim3(GLUE_THREADS), 0, (hipStream_t)stream, a, rays_o, rays_d, near,
+                     far, true_rgb, mask);
+  return avc_check_launch("avc_gen_rays");
+}
+
+// main.py:398-405: 0.2 / 0.8 chess board of L-pixel squares under torchvision's GaussianBlur(kernel (5, 9), sigma): separable taps with
+// reflect padding (5 along x, 9 along y), one thread per pixel.  taps: device [14] = kx[5], ky[9] (normalised, computed on the host).
+__device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+__global__ __launch_bounds__(GLUE_THREADS) void chess_bg_kernel(float* __restrict__ out, int H, int W, int L, const float* __restrict__ taps) {
+  const int t = blockIdx.x * GLUE_THREADS + threadIdx.x;
+  if (t >= H * W) return;
+  const int y = t / W, x = t % W;
+  float acc = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 9; ++ky) {
+    const int yy = reflect_idx(y + ky - 4, H);
+    float row = 0.f;
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx) {
+      const int xx = reflect_idx(x + kx - 2, W);
+      row += taps[kx] * ((((yy / L) + (xx / L)) & 1) == 0 ? 0.8f : 0.2f);
+    }
+    acc += taps[5 + ky] * row;
+  }
+  out[t] = acc;
+}
+extern "C" int avc_chess_background(float* out, int H, int W, int chess_length, const float* taps, void* stream) {
+  if (H <= 0 || W <= 0) return 0;
+  if (!out || !taps || chess_length < 1 || H < 5 || W < 3) { avc_set_error("avc_chess_background: bad arguments"); return 1; }
+  hipLaunchKernelGGL(chess_bg_kernel, dim3((H * W + GLUE_THREADS - 1) / GLUE_THREADS), dim3(GLUE_THREADS), 0, (hipStream_t)stream, out, H, W,
+                     chess_length, taps);
+  return avc_check_launch("avc_chess_background");
+}

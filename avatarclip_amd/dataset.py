@@ -141,25 +141,54 @@ class SMPL_Dataset:
         The reference dilates on the host (scipy.ndimage.binary_dilation, full 3x3 structure, 10 iterations = every pixel
         within Chebyshev distance 10 of the mask = a 21x21 maximum filter with zero border); here the filter runs on the
         device and the only host round trip left is the scalar that fixes the ray-grid size (a dynamic shape)."""
+        grid = self.silhouette_grid(max_ray_num, mask)
+        if grid is None:
+            return self.gen_rays_pose(pose, resolution_level=4)
+        Wn, sel, self.last_sel_idx = grid
+        dev = self.device
+        tx = torch.linspace(0, self.W - 1, Wn, device=dev)
+        ty = torch.linspace(0, self.H - 1, Wn, device=dev)
+        px, py = torch.meshgrid(tx, ty, indexing="ij")
+        o, v = self._dirs(px.t(), py.t(), torch.as_tensor(pose))
+        return o.reshape(-1, 3).index_select(0, self.last_sel_idx), v.reshape(-1, 3).index_select(0, self.last_sel_idx), Wn, sel
+
+    def silhouette_grid(self, max_ray_num, mask):
+        """the data-dependent half of gen_rays_silhouettes (dataset.py:252-275): -> (Wn = Hn of the ray grid, the selected pixels of
+        that grid as a bool image, their row-major positions), or None for an empty silhouette"""
         m0 = torch.as_tensor(mask, device=self.device)
         m0 = (m0 != 0).float()
         dilated = torch.nn.functional.max_pool2d(m0[None, None], kernel_size=21, stride=1, padding=10)[0, 0]
         n_mask, n_dilated = torch.stack([m0.sum(), dilated.sum()]).tolist()      # ONE round trip for both counts
         if n_mask == 0:
-            return self.gen_rays_pose(pose, resolution_level=4)
+            return None
         ratio = float(n_dilated) / float(m0.shape[0] * m0.shape[1])
         Wn = Hn = min(self.H, int(np.sqrt(max_ray_num / ratio)))
-        dev = self.device
-        tx = torch.linspace(0, self.W - 1, Wn, device=dev)
-        ty = torch.linspace(0, self.H - 1, Hn, device=dev)
-        px, py = torch.meshgrid(tx, ty, indexing="ij")
-        o, v = self._dirs(px.t(), py.t(), torch.as_tensor(pose))
         m = torch.nn.functional.interpolate(dilated.reshape(1, 1, *dilated.shape), size=(Hn, Wn)).squeeze()
         sel = m > 0
         # the row-major positions of the selected pixels: the second (and last) round trip -- it fixes the ray count.  Everything
         # downstream gathers / scatters with these indices (same order as boolean-mask indexing) without another synchronisation.
-        self.last_sel_idx = sel.reshape(-1).nonzero().squeeze(1)
-        return o.reshape(-1, 3).index_select(0, self.last_sel_idx), v.reshape(-1, 3).index_select(0, self.last_sel_idx), Wn, sel
+        return Wn, sel, sel.reshape(-1).nonzero().squeeze(1)
+
+    def rays_fused(self, pose, Wn, Hn, sel_idx=None, prior=None):
+        """gen_rays_pose on the Wn x Hn pixel grid (or its listed pixels) + near_far_from_sphere + the prior render resampled to the grid
+        (main.py:376-380), in ONE launch (csrc/avc_glue.hip: avc_gen_rays) -> rays_o, rays_d [R,3], near, far [R,1], true_rgb [Hn*Wn,3],
+        mask [Hn*Wn,1].  GPU only; the methods above are the torch statement the parity tests compare it with."""
+        from . import lib as L
+        dev = self.device
+        R = int(sel_idx.numel()) if sel_idx is not None else Wn * Hn
+        f32 = dict(device=dev, dtype=torch.float32)
+        rays_o, rays_d = torch.empty(R, 3, **f32), torch.empty(R, 3, **f32)
+        near, far = torch.empty(R, 1, **f32), torch.empty(R, 1, **f32)
+        true_rgb = mask = None
+        Hp = Wp = 0
+        if prior is not None:
+            prior = prior.contiguous().float()
+            Hp, Wp = prior.shape[0], prior.shape[1]
+            true_rgb, mask = torch.empty(Hn * Wn, 3, **f32), torch.empty(Hn * Wn, 1, **f32)
+        pose = torch.as_tensor(pose).to(dev).float().contiguous()
+        L.check(L.load().avc_gen_rays(L.ptr(pose), L.ptr(sel_idx), L.ptr(prior), Hp, Wp, float(self.W), float(self.H), float(self.focal), Wn, Hn, R,
+                                      L.ptr(rays_o), L.ptr(rays_d), L.ptr(near), L.ptr(far), L.ptr(true_rgb), L.ptr(mask), L.stream()), "avc_gen_rays")
+        return rays_o, rays_d, near, far, true_rgb, mask
 
     def near_far_from_sphere(self, rays_o, rays_d, is_sphere=False):
         """dataset.py:331-342 (`is_sphere` is ignored by the reference too)."""

@@ -177,6 +177,7 @@ class Engine:
     WG_BLOCKS_PER_SPLIT = int(os.environ.get("AVC_WG_BLOCKS_PER_SPLIT", "256"))     # split-K of the weight-gradient launch: blocks per workgroup (nsplit = blocks / this, 1..256).  A
                                   # 512^2 x 64 spp slab (262144 blocks) has its 256 splits either way; smaller point sets want the finer deal -- at 224^2 (100352
                                   # blocks) 256 splits x 17 pairs instead of 98 x 17 workgroups over 256 CUs: 8.52 -> 8.08 ms (profiles/r03_ab_kernels.txt)
+    WG_MAX_SPLITS = int(os.environ.get("AVC_WG_MAX_SPLITS", "256"))   # (<= 256: the size of the split buffers)
     MAX_FWD_WAVES = 2048          # persistent grid of avc_render_points_fwd: 256 CUs x one 8-wave workgroup
     MAX_BWD_WAVES = 2048          # 256 CUs x one 8-wave workgroup
     # Operand panels (csrc/avc_mlp.h: PanelLayout).  F region: 89 tiles = 5.6 KiB per point (full nets), written by the training
@@ -498,7 +499,7 @@ class Engine:
                         if int(rg["ctl"][64]) != 0:
                             raise RuntimeError("avc_render_points_bwd_ring: %d spin time-out(s), first site %d, counters %s"
                                                % (int(rg["ctl"][64]), int(rg["ctl"][65]), self.ring_stats))
-                ns = max(1, min(256, nblk // self.WG_BLOCKS_PER_SPLIT, nblk))
+                ns = max(1, min(self.WG_MAX_SPLITS, nblk // self.WG_BLOCKS_PER_SPLIT, nblk))
                 with Engine._Timed("avc_weight_grad(all pairs)", npts):
                     L.check(self.lib.avc_weight_grad_all(fptr, self.fwd_tiles, L.ptr(gpanels), self.grad_tiles, len(pairs_host),
                                                          pairs_host.ctypes.data, nblk, L.ptr(self._partials),

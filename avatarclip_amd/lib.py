@@ -48,6 +48,8 @@ _SIGS = {
     "avc_shade_loss_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P, P, P, P, P]),
     "avc_resize_norm_fwd": (c_int, [P, c_int, c_int, c_int, P, P, P, P]),
     "avc_resize_norm_bwd": (c_int, [P, c_int, c_int, c_int, P, P, P, P]),
+    "avc_gen_rays": (c_int, [P, P, P, c_int, c_int, c_float, c_float, c_float, c_int, c_int, c_int, P, P, P, P, P, P, P]),
+    "avc_chess_background": (c_int, [P, c_int, c_int, c_int, P, P]),
     "avc_bwd_ring_ctl_bytes": (c_long, []),
     "avc_bwd_ring_payload_bytes": (c_long, [c_int, c_int, c_int]),
     "avc_bwd_ring_types": (c_int, [c_int]),

@@ -383,6 +383,26 @@ class Runner:
         pose = h2d.upload(lookat(eye, at, np.array([0, 1, 0])), dev)
         prior = self.prior_renderer(eye, at)
         true_rgb = torch.as_tensor(prior, dtype=torch.float32, device=dev)
+        if dev.type == "cuda" and os.environ.get("AVC_FUSED_HEAD", "1") != "0":
+            # rays + near / far + the prior resampled to the ray grid in one launch (dataset.rays_fused) instead of ~45
+            dilated_mask = sel_idx = None
+            if self.use_silhouettes:
+                grid = self.dataset.silhouette_grid(self.max_ray_num, true_rgb[..., 0])
+                if grid is not None:
+                    W, dilated_mask, sel_idx = grid
+                    H = W
+                else:
+                    raise RuntimeError("the prior render of this view is empty: no silhouette to sample rays in (dataset.py:262-263)")
+            else:
+                W, H = int(self.dataset.W // self.full_frame_resolution_level), int(self.dataset.H // self.full_frame_resolution_level)
+            rays_o, rays_d, near, far, true_rgb, mask = self.dataset.rays_fused(pose, W, H, sel_idx, true_rgb.reshape(true_rgb.shape[0], true_rgb.shape[1], 3))
+            ray_of_pixel = None
+            if sel_idx is not None:
+                ray_of_pixel = torch.full((H * W,), -1, dtype=torch.int32, device=dev)
+                ray_of_pixel[sel_idx] = torch.arange(sel_idx.numel(), dtype=torch.int32, device=dev)
+            return types.SimpleNamespace(eye=eye, at=at, theta=theta, phi=phi, is_front=is_front, pose=pose, H=H, W=W,
+                                         rays_o=rays_o, rays_d=rays_d, near=near, far=far, true_rgb=true_rgb, mask=mask,
+                                         dilated_mask=dilated_mask, sel_idx=sel_idx, ray_of_pixel=ray_of_pixel)
         ori_mask = (true_rgb != 0).float()[..., 0]
         dilated_mask = sel_idx = None
         if self.use_silhouettes:
@@ -496,7 +516,8 @@ class Runner:
         elif choice_i == 2:
             chess_length = H // np.random.choice(np.arange(10, 20))
             sigma = torch.empty(1).uniform_(0.1, 2.0).item()   # torchvision GaussianBlur.get_params: torch CPU RNG
-            background_rgb = chess_background(H, W, chess_length, sigma, dev)
+            background_rgb = chess_background_fused(H, W, chess_length, sigma, dev) if dev.type == "cuda" and os.environ.get("AVC_FUSED_HEAD", "1") != "0" \
+                else chess_background(H, W, chess_length, sigma, dev)
         if self.use_silhouettes and choice_i in (1, 2):
             idx = getattr(view, "sel_idx", None)      # (gather by index: boolean-mask indexing would synchronise the stream for the count)
             masked_background_rgb = background_rgb.reshape(-1, 1).index_select(0, idx) if idx is not None else \
@@ -967,6 +988,19 @@ def chess_background(H, W, chess_length, sigma, device):
     jj = torch.arange(W, device=device)[None, :] // chess_length
     chess_board[((ii + jj) % 2 == 0)] = 0.8
     return _gaussian_blur(chess_board.permute(2, 0, 1).unsqueeze(0), (5, 9), float(sigma)).squeeze(0).permute(1, 2, 0).reshape(-1, 1)
+
+
+def chess_background_fused(H, W, chess_length, sigma, device):
+    """chess_background in one launch (csrc/avc_glue.hip: avc_chess_background; the 14 blur taps are computed on the host)"""
+    from . import lib as L
+    def k1d(k):
+        r = np.arange(k, dtype=np.float32) - np.float32((k - 1) / 2)
+        w = np.exp(np.float32(-0.5) * (r / np.float32(sigma)) ** 2).astype(np.float32)
+        return w / w.sum(dtype=np.float32)
+    taps = h2d.upload(np.concatenate([k1d(5), k1d(9)]), device)
+    out = torch.empty(H * W, 1, device=device, dtype=torch.float32)
+    L.check(L.load().avc_chess_background(L.ptr(out), H, W, int(chess_length), L.ptr(taps), L.stream()), "avc_chess_background")
+    return out
 
 
 def _gaussian_blur(x, ksize, sigma):

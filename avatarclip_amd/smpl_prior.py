@@ -74,16 +74,16 @@ class MeshPrior:
     def render_grey(self, eye, direction):
         """nr.Renderer(camera_mode='look')(vertices, faces, ones) -> [S,S] grey image (before the x flip)"""
         dev = self.device
-        eye = h2d.upload(np.asarray(eye, np.float32), dev)
-        z = h2d.upload(np.asarray(direction, np.float32), dev)
-        z = z / z.norm()
-        up = h2d.const([0.0, 1.0, 0.0], dev)
-        x = torch.linalg.cross(up, z)
-        x = x / x.norm()
-        y = torch.linalg.cross(z, x)
-        y = y / y.norm()
-        r = torch.stack([x, y, z])                                  # neural_renderer/look.py
-        v = (self.v_world - eye) @ r.t()
+        # neural_renderer/look.py: the camera frame, in float32 like there -- on the host (a dozen small launches otherwise), one upload
+        f = np.float32
+        z = np.asarray(direction, f)
+        z = z / f(np.sqrt((z * z).sum(dtype=f)))
+        x = np.cross(np.array([0.0, 1.0, 0.0], f), z).astype(f)
+        x = x / f(np.sqrt((x * x).sum(dtype=f)))
+        y = np.cross(z, x).astype(f)
+        y = y / f(np.sqrt((y * y).sum(dtype=f)))
+        cam = h2d.upload(np.concatenate([np.asarray(eye, f), x, y, z]), dev)
+        v = (self.v_world - cam[:3]) @ cam[3:].reshape(3, 3).t()
         ndc = torch.stack([v[:, 0] / v[:, 2] / self.width, v[:, 1] / v[:, 2] / self.width, v[:, 2]], dim=1)   # perspective.py
         fz = ndc[self.faces2].reshape(-1, 9).contiguous()
         S2 = 2 * self.image_size                                    # anti_aliasing=True

@@ -164,6 +164,17 @@ int avc_shade_loss_bwd(const float* color, const float* extra, const float* wsum
 int avc_resize_norm_fwd(const float* images, int B, int H, int W, const float* mean, const float* stdv, float* out, void* stream);
 int avc_resize_norm_bwd(const float* dout, int B, int H, int W, const float* mean, const float* stdv, float* dimages, void* stream);
 
+/* The rays of a view in one launch (dataset.py:277-293 gen_rays_pose: pixel centres linspace(0, W - 1, Wn) x linspace(0, H - 1, Hn) of the
+ * dataset's pinhole camera (W, H, focal), direction = pose[:3,:3] p / |p| with p = ((x - W/2) / f, -(y - H/2) / f, -1), origin = pose[:3,3];
+ * sel != NULL: only the R listed row-major pixels, the selected rays of gen_rays_silhouettes :252-275) with near / far from the unit
+ * sphere (:331-342), and -- prior != NULL -- the prior render [Hp,Wp,3] resampled to the Hn x Wn grid (main.py:376-380: nearest) as
+ * true_rgb [Hn*Wn,3] and mask [Hn*Wn] = (true_rgb[..., 0] != 0).  pose: device [16], camera-to-world, row major. */
+int avc_gen_rays(const float* pose, const long* sel, const float* prior, int Hp, int Wp, float W, float H, float focal, int Wn, int Hn,
+                 int R, float* rays_o, float* rays_d, float* near, float* far, float* true_rgb, float* mask, void* stream);
+/* main.py:398-405: the blurred chess-board background of the augmentation, out [H*W] (0.2 / 0.8 squares of chess_length pixels,
+ * GaussianBlur kernel (5, 9) with reflect padding; taps = device [14]: the 5 normalised taps along x, then the 9 along y). */
+int avc_chess_background(float* out, int H, int W, int chess_length, const float* taps, void* stream);
+
 /* Dense-parameter assembly of one optimisation step: W_l = g_l * v_l / ||v_l||_row (nn.utils.weight_norm, fields.py:65-66,139-143;
  * g[l] == NULL: the plain weight) and the biases of `n` linears written into the flat dense vector `flat` at w_off[l] (row-major
  * [rows, cols]) / b_off[l] (floats), and the backward of that map: dflat -> dv[l], dg[l], db[l] (b[l] / db[l] may be NULL).

@@ -106,3 +106,36 @@ def test_resize_norm_equals_interpolate(H):
     (ya * w).sum().backward()
     (yb * w).sum().backward()
     assert (a.grad - b.grad).abs().max() < 1e-4 * a.grad.abs().max()
+
+
+@gpu
+@pytest.mark.parametrize("silhouettes", [True, False])
+def test_fused_head_equals_the_torch_statement(silhouettes, monkeypatch):
+    """Runner.make_view through dataset.rays_fused (rays, near / far and the resampled prior in one launch) against the torch statement
+    of dataset.py:252-293,331-342 and main.py:376-380 -- which tests/test_host_logic.py pins against the reference's own functions."""
+    dev = torch.device("cuda")
+    r = _runner(silhouettes, True, True, dev)
+    cam = r.sample_camera(1)
+    views = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("AVC_FUSED_HEAD", fused)
+        views.append(r.make_view(1, camera=cam))
+    a, b = views
+    assert (a.H, a.W) == (b.H, b.W) and a.rays_o.shape == b.rays_o.shape
+    for k in ("rays_o", "rays_d", "near", "far", "true_rgb", "mask"):
+        x, y = getattr(a, k), getattr(b, k)
+        assert x.shape == y.shape, k
+        assert (x - y).abs().max() < 2e-6, (k, (x - y).abs().max())
+    if silhouettes:
+        assert torch.equal(a.sel_idx, b.sel_idx) and torch.equal(a.dilated_mask, b.dilated_mask) and torch.equal(a.ray_of_pixel, b.ray_of_pixel)
+
+
+@gpu
+def test_fused_chess_background_equals_the_torch_statement():
+    from avatarclip_amd import runner as RN
+    dev = torch.device("cuda")
+    for H, W, L, sigma in ((190, 190, 13, 0.7), (224, 224, 11, 1.9), (64, 80, 5, 0.1)):
+        a = RN.chess_background(H, W, L, sigma, dev)
+        b = RN.chess_background_fused(H, W, L, sigma, dev)
+        assert a.shape == b.shape == (H * W, 1)
+        assert (a - b).abs().max() < 2e-6

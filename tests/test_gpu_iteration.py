@@ -64,6 +64,8 @@ def _check_grads(names, grads_a, grads_b, sdf_last_bias, rel_tol, cos_tol, bias_
         if gb.double().norm() < 1e-3 * gnorm:
             cos = 1.0
         worst = max(worst, rel)
+        if os.environ.get("AVC_TEST_VERBOSE"):
+            print("    %-24s rel %.3e cos %.6f |ref| %.3e" % (n, rel, cos, gb.double().norm().item()))
         assert rel < rel_tol and cos > cos_tol, (n, rel, cos)
     return worst
 

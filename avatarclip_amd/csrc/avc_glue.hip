@@ -64,10 +64,12 @@ __device__ __forceinline__ Shade shade_pixel(const GlueIn& g, int r) {
 }
 
 // images [2][P][3]: 0 = texture_shading (or extra_color when there is no shading), 1 = rand_shading_rgb;
-// partial [gridDim.x][4] = per-block sums of (|color - true| mask, mask, BCE term, 0)
-__global__ __launch_bounds__(GLUE_THREADS) void shade_loss_fwd_kernel(GlueIn g, float* __restrict__ images, float* __restrict__ partial) {
+// partial [gridDim.x][4] = per-block sums of (|color - true| mask, mask, BCE term, (color - true)^2 mask); the block that finishes
+// last (ticket: a zero-initialised device word that it resets) adds the partials up in a fixed order into sums[4]
+__global__ __launch_bounds__(GLUE_THREADS) void shade_loss_fwd_kernel(GlueIn g, float* __restrict__ images, float* __restrict__ partial,
+                                                                      float* __restrict__ sums, unsigned* __restrict__ ticket) {
   const int p = blockIdx.x * GLUE_THREADS + threadIdx.x;
-  float l1 = 0.f, ms = 0.f, bce = 0.f;
+  float l1 = 0.f, ms = 0.f, bce = 0.f, sq = 0.f;
   if (p < g.P) {
     const int r = g.ray_of_pixel ? g.ray_of_pixel[p] : p;
     float C[3] = {0.f, 0.f, 0.f}, ws = 0.f;
@@ -87,26 +89,57 @@ __global__ __launch_bounds__(GLUE_THREADS) void shade_loss_fwd_kernel(GlueIn g, 
     for (int c = 0; c < 3; ++c) {
       images[(long)p * 3 + c] = i0[c];
       images[((long)g.P + p) * 3 + c] = i1[c];
-      l1 += fabsf((C[c] - g.true_rgb[3 * p + c]) * m);
+      const float e = (C[c] - g.true_rgb[3 * p + c]);
+      l1 += fabsf(e * m);
+      sq += e * e * m;
     }
     ms = m;
     const float x = fminf(fmaxf(ws, 1e-3f), 1.f - 1e-3f);
     bce = -(m * fmaxf(logf(x), -100.f) + (1.f - m) * fmaxf(logf(1.f - x), -100.f));   // F.binary_cross_entropy (log clamped at -100)
   }
-  __shared__ float red[3][GLUE_THREADS / 64];
+  __shared__ float red[4][GLUE_THREADS / 64];
+  __shared__ bool last;
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) { l1 += __shfl_xor(l1, d); ms += __shfl_xor(ms, d); bce += __shfl_xor(bce, d); }
+  for (int d = 32; d >= 1; d >>= 1) { l1 += __shfl_xor(l1, d); ms += __shfl_xor(ms, d); bce += __shfl_xor(bce, d); sq += __shfl_xor(sq, d); }
   const int wv = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { red[0][wv] = l1; red[1][wv] = ms; red[2][wv] = bce; }
+  if ((threadIdx.x & 63) == 0) { red[0][wv] = l1; red[1][wv] = ms; red[2][wv] = bce; red[3][wv] = sq; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    float a = 0.f, b = 0.f, c = 0.f;
-    for (int w = 0; w < GLUE_THREADS / 64; ++w) { a += red[0][w]; b += red[1][w]; c += red[2][w]; }
-    partial[4 * blockIdx.x + 0] = a; partial[4 * blockIdx.x + 1] = b; partial[4 * blockIdx.x + 2] = c; partial[4 * blockIdx.x + 3] = 0.f;
+    float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+    for (int w = 0; w < GLUE_THREADS / 64; ++w) { a += red[0][w]; b += red[1][w]; c += red[2][w]; d += red[3][w]; }
+    partial[4 * blockIdx.x + 0] = a; partial[4 * blockIdx.x + 1] = b; partial[4 * blockIdx.x + 2] = c; partial[4 * blockIdx.x + 3] = d;
+    __threadfence();                                        // the partials are visible device-wide before the ticket moves
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
   }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  // fixed order: thread t adds the blocks t, t + 256, ...; then the lanes of a wave, then the four waves
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int b = threadIdx.x; b < (int)gridDim.x; b += GLUE_THREADS) {
+    const f4 v = reinterpret_cast<const f4*>(partial)[b];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] += v[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc[k] += __shfl_xor(acc[k], d);
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[k][wv] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    float v = 0.f;
+    for (int w = 0; w < GLUE_THREADS / 64; ++w) v += red[threadIdx.x][w];
+    sums[threadIdx.x] = v;
+  }
+  if (threadIdx.x == 0) *ticket = 0u;
 }
 
-// gs (device [2]) = d loss / d (l1 sum), d loss / d (bce sum); dimages [2][P][3] (either half may be NULL: that image is not used)
+// gs (device [4], the gradient of the forward's sums) : [0] = d loss / d (l1 sum), [2] = d loss / d (bce sum); dimages [2][P][3] (either half may be NULL: that image is not used)
 __global__ __launch_bounds__(GLUE_THREADS) void shade_loss_bwd_kernel(GlueIn g, const float* __restrict__ dimg0, const float* __restrict__ dimg1,
                                                                       const float* __restrict__ gs, float* __restrict__ dcolor,
                                                                       float* __restrict__ dextra, float* __restrict__ dwsum, float* __restrict__ dnsum) {
@@ -114,7 +147,7 @@ __global__ __launch_bounds__(GLUE_THREADS) void shade_loss_bwd_kernel(GlueIn g, 
   if (p >= g.P) return;
   const int r = g.ray_of_pixel ? g.ray_of_pixel[p] : p;
   if (r < 0) return;
-  const float m = g.mask[p], gl1 = gs[0], gbce = gs[1];
+  const float m = g.mask[p], gl1 = gs[0], gbce = gs[2];
   // colour L1: d |e| = sign(e), e = (C - T) m
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -177,11 +210,15 @@ static GlueIn glue_in(const float* color, const float* extra, const float* wsum,
 
 extern "C" int avc_shade_loss_fwd(const float* color, const float* extra, const float* wsum, const float* nsum, const float* true_rgb,
                                   const float* mask, const int* ray_of_pixel, const float* bg, float bg_const, const float* light, int P,
-                                  int img0_is_extra, float* images, float* partial, void* stream) {
+                                  int img0_is_extra, float* images, float* partial, float* sums, unsigned* ticket, void* stream) {
   if (P <= 0) return 0;
-  if (!color || !extra || !wsum || !true_rgb || !mask || !images || !partial || (nsum && !light)) { avc_set_error("avc_shade_loss_fwd: NULL buffer"); return 1; }
+  if (!color || !extra || !wsum || !true_rgb || !mask || !images || !partial || !sums || !ticket || (nsum && !light)) {
+    avc_set_error("avc_shade_loss_fwd: NULL buffer");
+    return 1;
+  }
   hipLaunchKernelGGL(shade_loss_fwd_kernel, dim3(avc_shade_loss_blocks(P)), dim3(GLUE_THREADS), 0, (hipStream_t)stream,
-                     glue_in(color, extra, wsum, nsum, true_rgb, mask, ray_of_pixel, bg, bg_const, light, P, img0_is_extra), images, partial);
+                     glue_in(color, extra, wsum, nsum, true_rgb, mask, ray_of_pixel, bg, bg_const, light, P, img0_is_extra), images, partial,
+                     sums, ticket);
   return avc_check_launch("avc_shade_loss_fwd");
 }
 
@@ -386,4 +423,91 @@ extern "C" int avc_chess_background(float* out, int H, int W, int chess_length, 
   hipLaunchKernelGGL(chess_bg_kernel, dim3((H * W + GLUE_THREADS - 1) / GLUE_THREADS), dim3(GLUE_THREADS), 0, (hipStream_t)stream, out, H, W,
                      chess_length, taps);
   return avc_check_launch("avc_chess_background");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The scalar tail of the iteration's loss (main.py:491-534) in one launch each way: the two CLIP cosines
+//   cos_b = < e_b / max(|e_b|, 1e-8), t / max(|t|, 1e-8) >,   e_b = torch.mean(enc[b:b+1], dim=0), t = torch.mean(text, dim=0)
+// (torch.cosine_similarity normalises first), the colour / mask terms from the sums of avc_shade_loss_fwd and
+//   loss = l1 / (mask_sum + 1e-5) + eikonal * igr_weight + (bce / P) * mask_weight + sum_b (1 - cos_b) * clip_weight
+// in the reference's order of additions.  One 512-thread block, thread = embedding channel.
+#define TAIL_D 512
+struct TailW { float igr_w, mask_w, clip_w, P; };
+__device__ __forceinline__ float tail_block_sum(float v, float (*red)[TAIL_D / 64], int slot) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  if ((threadIdx.x & 63) == 0) red[slot][threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < TAIL_D / 64; ++w) t += red[slot][w];
+  return t;
+}
+// out[8] = loss, colour loss, mask loss, cos_0, cos_1, 0, 0, 0;  saved[4 B] = per image (|e| clamped, cos, |e| raw, 0); saved[4 B] = |t| clamped
+__global__ __launch_bounds__(TAIL_D) void loss_tail_fwd_kernel(const float* __restrict__ enc, const float* __restrict__ text, int B, int T,
+                                                               const float* __restrict__ sums, const float* __restrict__ eik, TailW w,
+                                                               float* __restrict__ loss, float* __restrict__ out, float* __restrict__ saved) {
+  __shared__ float red[2 + 2 * 4][TAIL_D / 64];
+  const int c = threadIdx.x;
+  float tm = 0.f;
+  for (int t = 0; t < T; ++t) tm += text[(long)t * TAIL_D + c];
+  tm /= (float)T;
+  const float nt = fmaxf(sqrtf(tail_block_sum(tm * tm, red, 0)), 1e-8f);
+  const float th = tm / nt;
+  float cosv[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < B; ++b) {
+    const float e = enc[(long)b * TAIL_D + c];
+    const float nr = sqrtf(tail_block_sum(e * e, red, 2 + 2 * b)), ne = fmaxf(nr, 1e-8f);
+    const float cs = tail_block_sum((e / ne) * th, red, 3 + 2 * b);
+    cosv[b] = cs;
+    if (c == 0) { saved[4 * b] = ne; saved[4 * b + 1] = cs; saved[4 * b + 2] = nr; saved[4 * b + 3] = 0.f; }
+  }
+  if (c == 0) {
+    saved[4 * B] = nt;
+    const float colour = sums[0] / (sums[1] + 1e-5f), maskl = sums[2] / w.P;
+    float l = colour + eik[0] * w.igr_w + maskl * w.mask_w;
+    for (int b = 0; b < B; ++b) l = l + (1.f - cosv[b]) * w.clip_w;
+    loss[0] = l;
+    out[0] = l; out[1] = colour; out[2] = maskl; out[3] = cosv[0]; out[4] = cosv[1]; out[5] = 0.f; out[6] = 0.f; out[7] = 0.f;
+  }
+}
+// g = d L / d loss (device scalar).  d_enc [B,512]; dd[8]: [0..3] = gradient of sums (l1, mask_sum: 0, bce, sq: 0), [4] = of the eikonal term
+__global__ __launch_bounds__(TAIL_D) void loss_tail_bwd_kernel(const float* __restrict__ g, const float* __restrict__ enc,
+                                                               const float* __restrict__ text, int B, int T, const float* __restrict__ sums,
+                                                               const float* __restrict__ saved, TailW w, float* __restrict__ d_enc,
+                                                               float* __restrict__ dd) {
+  const int c = threadIdx.x;
+  const float gl = g[0];
+  float tm = 0.f;
+  for (int t = 0; t < T; ++t) tm += text[(long)t * TAIL_D + c];
+  tm /= (float)T;
+  const float th = tm / saved[4 * B];
+  for (int b = 0; b < B; ++b) {
+    const float ne = saved[4 * b], cs = saved[4 * b + 1], nr = saved[4 * b + 2];
+    const float e = enc[(long)b * TAIL_D + c];
+    // cos = <e / ne, th>: d e = th / ne - (the norm's branch, only where the clamp is inactive) cos * e / ne^2
+    float d = th / ne;
+    if (nr > 1e-8f) d -= cs * e / (ne * ne);
+    d_enc[(long)b * TAIL_D + c] = -gl * w.clip_w * d;
+  }
+  if (c == 0) {
+    dd[0] = gl / (sums[1] + 1e-5f); dd[1] = 0.f; dd[2] = gl * w.mask_w / w.P; dd[3] = 0.f;
+    dd[4] = gl * w.igr_w; dd[5] = 0.f; dd[6] = 0.f; dd[7] = 0.f;
+  }
+}
+extern "C" int avc_loss_tail_fwd(const float* enc, const float* text, int B, int T, int D, const float* sums, const float* eikonal, float igr_weight,
+                                 float mask_weight, float clip_weight, float P, float* loss, float* out, float* saved, void* stream) {
+  if (D != TAIL_D || B < 1 || B > 4 || T < 1) { avc_set_error("avc_loss_tail_fwd: built for 512-wide embeddings, 1-4 images"); return 1; }
+  if (!enc || !text || !sums || !eikonal || !loss || !out || !saved) { avc_set_error("avc_loss_tail_fwd: NULL buffer"); return 1; }
+  const TailW w = {igr_weight, mask_weight, clip_weight, P};
+  hipLaunchKernelGGL(loss_tail_fwd_kernel, dim3(1), dim3(TAIL_D), 0, (hipStream_t)stream, enc, text, B, T, sums, eikonal, w, loss, out, saved);
+  return avc_check_launch("avc_loss_tail_fwd");
+}
+extern "C" int avc_loss_tail_bwd(const float* g, const float* enc, const float* text, int B, int T, int D, const float* sums, const float* saved,
+                                 float igr_weight, float mask_weight, float clip_weight, float P, float* d_enc, float* dd, void* stream) {
+  if (D != TAIL_D || B < 1 || B > 4 || T < 1) { avc_set_error("avc_loss_tail_bwd: built for 512-wide embeddings, 1-4 images"); return 1; }
+  if (!g || !enc || !text || !sums || !saved || !d_enc || !dd) { avc_set_error("avc_loss_tail_bwd: NULL buffer"); return 1; }
+  const TailW w = {igr_weight, mask_weight, clip_weight, P};
+  hipLaunchKernelGGL(loss_tail_bwd_kernel, dim3(1), dim3(TAIL_D), 0, (hipStream_t)stream, g, enc, text, B, T, sums, saved, w, d_enc, dd);
+  return avc_check_launch("avc_loss_tail_bwd");
 }

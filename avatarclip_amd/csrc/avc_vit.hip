@@ -54,7 +54,8 @@ template <int MT>
 __global__ __launch_bounds__(64 * VIT_WAVES) void vit_linear_kernel(const b8* __restrict__ Xs, const b8* __restrict__ Wp,
                                                                     const float* __restrict__ bias, const float* __restrict__ res,
                                                                     float* __restrict__ Y, float* __restrict__ Ypre, int M, int N,
-                                                                    int K, int act) {
+                                                                    int K, int act, __bf16* __restrict__ Ys = nullptr,
+                                                                    const float* __restrict__ gpre = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [VIT_WAVES][MT][16][64]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int n = lane & 31, h = lane >> 5;
@@ -101,10 +102,19 @@ __global__ __launch_bounds__(64 * VIT_WAVES) void vit_linear_kernel(const b8* __
       if (act == 1) {
         if (Ypre) Ypre[o] = v;
         v = v * sigmoidf_(1.702f * v);
+      } else if (act == 2) {          // backward of a QuickGELU layer: this product is the gradient of its OUTPUT
+        const float p = gpre[o], sg = sigmoidf_(1.702f * p);
+        v *= sg + 1.702f * p * sg * (1.f - sg);
       }
       if (res) v += res[o];
-      Y[o] = v;
+      if (Y) Y[o] = v;
+    } else {
+      v = 0.f;
     }
+    // the per-iteration training pipeline (avc_vit_linear_small): the result leaves (also) as the packed bf16 operand of the linear
+    // behind it -- element (row, col) is slot col & 7 of lane (row & 31, (col >> 3) & 1) of k-step col >> 4 of row tile row >> 5; the
+    // rows of the last tile past M are written as zeros
+    if (Ys) Ys[((((long)(row >> 5)) * (N >> 4) + (col >> 4)) * 64 + (row & 31) + 32 * ((col >> 3) & 1)) * 8 + (col & 7)] = (__bf16)v;
   }
 }
 
@@ -287,10 +297,63 @@ __global__ __launch_bounds__(256) void vit_ln_pack_kernel(const float* __restric
   const int n = lane & 31, h = lane >> 5;
   for (int s = wv; s < KS; s += 4) xs[((long)mt * KS + s) * 64 + lane] = *reinterpret_cast<const b8*>(&tile[n][16 * s + 8 * h]);
 }
+// Up to 128 rows (the per-iteration calls) the tile kernel above is four workgroups walking 8 rows per wavefront one after the
+// other -- a latency chain.  Here: one wavefront per row, all of a row's loads in flight at once, and no LDS: a lane holds 4
+// consecutive columns of its row = one 8-byte half of a packed 16-byte chunk (column c of row r is slot c & 7 of lane (r & 31,
+// (c >> 3) & 1) of k-step c >> 4 of row tile r >> 5).  Rows past M are not touched (the caller's buffer holds zeros there).
+__device__ __forceinline__ void ln_row_stats(f4 (&v)[3], float eps, float& rstd) {   // on return v = x - mean
+  constexpr int K = 768;
+  float s1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) s1 += v[c][0] + v[c][1] + v[c][2] + v[c][3];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) s1 += __shfl_xor(s1, d);
+  const float mean = s1 * (1.f / K);
+  float s2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { v[c][u] -= mean; s2 += v[c][u] * v[c][u]; }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) s2 += __shfl_xor(s2, d);
+  rstd = rsqrtf(s2 * (1.f / K) + eps);
+}
+__device__ __forceinline__ void put_packed4(b8* xs, int row, int col, f4 v) {   // 4 consecutive columns from col (col % 4 == 0), K = 768
+  typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+  bf4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  char* p = reinterpret_cast<char*>(xs + (((long)(row >> 5)) * 48 + (col >> 4)) * 64 + (row & 31) + 32 * ((col >> 3) & 1)) + 2 * (col & 7);
+  *reinterpret_cast<bf4*>(p) = o;
+}
+__global__ __launch_bounds__(256) void vit_ln_pack_rows_kernel(const float* __restrict__ X, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, b8* __restrict__ xs, int M) {
+  constexpr int K = 768;
+  const int lane = threadIdx.x & 63, row = 4 * blockIdx.x + (threadIdx.x >> 6);
+  if (row >= M) return;
+  f4 v[3], g[3], bt[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    v[c] = *reinterpret_cast<const f4*>(X + (long)row * K + 4 * (lane + 64 * c));
+    g[c] = *reinterpret_cast<const f4*>(gamma + 4 * (lane + 64 * c));
+    bt[c] = *reinterpret_cast<const f4*>(beta + 4 * (lane + 64 * c));
+  }
+  float rstd;
+  ln_row_stats(v, eps, rstd);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    f4 o;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) o[u] = v[c][u] * rstd * g[c][u] + bt[c][u];
+    put_packed4(xs, row, 4 * (lane + 64 * c), o);
+  }
+}
 extern "C" int avc_vit_ln_pack(const float* x, const float* gamma, const float* beta, float eps, int M, int K, void* xs_packed,
                                void* stream) {
   if (K != 768) { avc_set_error("avc_vit_ln_pack: built for the ViT-B/32 width 768"); return 1; }
   if (M <= 0) return 0;
+  if (M <= 32 * VIT_MAX_MT) {
+    hipLaunchKernelGGL(vit_ln_pack_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps, (b8*)xs_packed, M);
+    return avc_check_launch("avc_vit_ln_pack");
+  }
   const int mt = ((M + 127) / 128) * 4;          // the row-tile groups of avc_vit_workspace_bytes (rows past M: LayerNorm of zeros = beta)
   hipLaunchKernelGGL(vit_ln_pack_kernel, dim3(mt), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps, (b8*)xs_packed, M);
   return avc_check_launch("avc_vit_ln_pack");
@@ -306,6 +369,76 @@ extern "C" int avc_vit_linear_packed(const void* xs_packed, const void* w_packed
     return 1;
   }
   return avc_check_launch("avc_vit_linear_packed");
+}
+
+// ---- the per-iteration training pipeline (1-2 images WITH a gradient to the pixels, M <= 128 rows): the same packed hand-offs for
+// the latency kernel, forward and backward (clip_vit.BlocksFn).  Per block 7 launches forward (ln_pack, qkv, attention, out +
+// residual, ln_pack, fc -> pre + packed QuickGELU, proj + residual) and 9 backward instead of 11 + 14 torch-autograd nodes with a
+// packing launch in front of every linear, torch LayerNorm kernels and AccumulateGrad adds between them.
+extern "C" int avc_vit_pack(const float* x, const float* gelu_pre, void* xs_packed, int M, int K, void* stream) {
+  if (M <= 0) return 0;
+  if (K & 15) { avc_set_error("avc_vit_pack: need K % 16 == 0"); return 1; }
+  const int mt = (M + 31) / 32;
+  hipLaunchKernelGGL(vit_pack_x_kernel, dim3(K / 16, mt), dim3(64), 0, (hipStream_t)stream, x, gelu_pre, (b8*)xs_packed, M, K);
+  return avc_check_launch("avc_vit_pack");
+}
+// y = f(xs W^T + b) (+ residual), M <= 128 rows, from a packed operand.  act 0: identity; 1: QuickGELU (y_pre, if given, receives
+// the pre-activation); 2: times QuickGELU'(gelu_pre[M,N]) (the backward of a QuickGELU layer folded into the product that yields the
+// gradient of its output).  y (fp32 rows) and ys_packed (the operand of the next linear) are both optional.
+extern "C" int avc_vit_linear_small(const void* xs_packed, const void* w_packed, const float* bias, const float* residual,
+                                    const float* gelu_pre, float* y, float* y_pre, void* ys_packed, int M, int N, int K, int act,
+                                    void* stream) {
+  if (M <= 0) return 0;
+  if (M > 32 * VIT_MAX_MT || (N & 31) || (K & 15)) { avc_set_error("avc_vit_linear_small: need M <= 128, N % 32 == 0, K % 16 == 0"); return 1; }
+  if ((act == 2) != (gelu_pre != nullptr) || (!y && !ys_packed)) { avc_set_error("avc_vit_linear_small: act 2 <=> gelu_pre; y or ys_packed"); return 1; }
+  const int mt = (M + 31) / 32;
+  hipLaunchKernelGGL((vit_linear_kernel<1>), dim3(N / 32, mt), dim3(64 * VIT_WAVES), VIT_WAVES * 4096, (hipStream_t)stream,
+                     (const b8*)xs_packed, (const b8*)w_packed, bias, residual, y, y_pre, M, N, K, act, (__bf16*)ys_packed, gelu_pre);
+  return avc_check_launch("avc_vit_linear_small");
+}
+// backward of LayerNorm over the last dimension (768) + the residual branch's gradient: dx = LN'(x; gamma)^T dy (+ res), written as
+// fp32 rows and (xs_packed != NULL) as the packed operand of the transposed linear that consumes it.  Statistics recomputed from x
+// in fp32 (two-pass, like vit_ln_pack_kernel); one wavefront per row (vit_ln_pack_rows_kernel); rows past M of xs are not touched.
+__global__ __launch_bounds__(256) void vit_ln_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+                                                         const float* __restrict__ gamma, float eps, const float* __restrict__ res,
+                                                         float* __restrict__ dX, b8* __restrict__ xs, int M) {
+  constexpr int K = 768;
+  const int lane = threadIdx.x & 63, row = 4 * blockIdx.x + (threadIdx.x >> 6);
+  if (row >= M) return;
+  f4 v[3], gy[3], rs[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const long o = (long)row * K + 4 * (lane + 64 * c);
+    v[c] = *reinterpret_cast<const f4*>(X + o);
+    gy[c] = *reinterpret_cast<const f4*>(dY + o) * *reinterpret_cast<const f4*>(gamma + 4 * (lane + 64 * c));
+    rs[c] = res ? *reinterpret_cast<const f4*>(res + o) : f4{0.f, 0.f, 0.f, 0.f};
+  }
+  float rstd;
+  ln_row_stats(v, eps, rstd);
+  float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { v[c][u] *= rstd; c1 += gy[c][u]; c2 += gy[c][u] * v[c][u]; }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { c1 += __shfl_xor(c1, d); c2 += __shfl_xor(c2, d); }
+  c1 *= 1.f / K; c2 *= 1.f / K;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    f4 dx;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) dx[u] = rstd * (gy[c][u] - c1 - v[c][u] * c2) + rs[c][u];
+    *reinterpret_cast<f4*>(dX + (long)row * K + 4 * (lane + 64 * c)) = dx;
+    if (xs) put_packed4(xs, row, 4 * (lane + 64 * c), dx);
+  }
+}
+extern "C" int avc_vit_ln_bwd(const float* dy, const float* x, const float* gamma, float eps, const float* residual_grad, float* dx,
+                              void* xs_packed, int M, int K, void* stream) {
+  if (K != 768) { avc_set_error("avc_vit_ln_bwd: built for the ViT-B/32 width 768"); return 1; }
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(vit_ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, eps, residual_grad, dx,
+                     (b8*)xs_packed, M);
+  return avc_check_launch("avc_vit_ln_bwd");
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -35,6 +35,9 @@ _SIGS = {
     "avc_vit_workspace_bytes": (c_long, [c_int, c_int]),
     "avc_vit_ln_pack": (c_int, [P, P, P, c_float, c_int, c_int, P, P]),
     "avc_vit_linear_packed": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "avc_vit_pack": (c_int, [P, P, P, c_int, c_int, P]),
+    "avc_vit_linear_small": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "avc_vit_ln_bwd": (c_int, [P, P, P, c_float, P, P, P, c_int, c_int, P]),
     "avc_vit_attention_fwd_packed": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "avc_vit_attention_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "avc_vit_attention_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
@@ -44,7 +47,9 @@ _SIGS = {
     "avc_dense_params_bwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P]),
     "avc_weight_grad_all": (c_int, [P, c_int, P, c_int, c_int, P, c_long, P, P, c_int, c_int, c_int, P]),
     "avc_shade_loss_blocks": (c_int, [c_int]),
-    "avc_shade_loss_fwd": (c_int, [P, P, P, P, P, P, P, P, c_float, P, c_int, c_int, P, P, P]),
+    "avc_shade_loss_fwd": (c_int, [P, P, P, P, P, P, P, P, c_float, P, c_int, c_int, P, P, P, P, P]),
+    "avc_loss_tail_fwd": (c_int, [P, P, c_int, c_int, c_int, P, P, c_float, c_float, c_float, c_float, P, P, P, P]),
+    "avc_loss_tail_bwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P, c_float, c_float, c_float, c_float, P, P, P]),
     "avc_shade_loss_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P, P, P, P, P]),
     "avc_resize_norm_fwd": (c_int, [P, c_int, c_int, c_int, P, P, P, P]),
     "avc_resize_norm_bwd": (c_int, [P, c_int, c_int, c_int, P, P, P, P]),

@@ -645,16 +645,13 @@ class Runner:
             elif choice_i in (1, 2):
                 bg = background_rgb.reshape(-1)
         mask = (view.mask > 0.5).float() if self.mask_weight > 0.0 else torch.ones_like(view.mask)
-        images, l1, mask_sum, bce, sq = glue.ShadeLossFn.apply(
+        images, sums = glue.ShadeLossFn.apply(
             render_out["color_fine"], render_out["extra_color_fine"], render_out["weight_sum"].reshape(-1), nsum, view.true_rgb,
             mask.reshape(-1), rop, bg, bg_const, light4, not self.texture_cast_light)
-        mask_sum = mask_sum + 1e-5
-        color_fine_loss = l1 / mask_sum
-        mask_loss = bce / P
         psnr = None
         if self.writer is not None:   # main.py:493 (a logged statistic only)
             with torch.no_grad():
-                psnr = 20.0 * torch.log10(1.0 / (sq / (mask_sum * 3.0)).sqrt())
+                psnr = 20.0 * torch.log10(1.0 / (sums[3] / ((sums[1] + 1e-5) * 3.0)).sqrt())
         eikonal_loss = render_out["gradient_error"]
         if self.use_face_prompt and iter_i % 4 == 0:
             text = self.encoded_face_text
@@ -664,13 +661,9 @@ class Runner:
             text = self.encoded_text
         B = 2 if self.add_no_texture else 1
         enc_both = self.perceptor.encode_image(glue.ResizeNormFn.apply(images[:B].reshape(B, H, W, 3)))
-        cosine = torch.cosine_similarity(torch.mean(enc_both[0:1], dim=0), torch.mean(text, dim=0), dim=0)
-        loss = color_fine_loss + eikonal_loss * self.igr_weight + mask_loss * self.mask_weight + (1.0 - cosine) * self.clip_weight
-        cosine_shading = None
-        if self.add_no_texture:
-            cosine_shading = torch.cosine_similarity(torch.mean(enc_both[1:2], dim=0), torch.mean(text, dim=0), dim=0)
-            loss = loss + (1.0 - cosine_shading) * self.clip_weight
-        return loss, dict(color=color_fine_loss, eikonal=eikonal_loss, mask=mask_loss, cosine=cosine, cosine_shading=cosine_shading,
+        # main.py:491-534 from here on (colour / mask normalisation, the cosines, the weighted sum) in one launch: glue.LossTailFn
+        loss, st = glue.LossTailFn.apply(enc_both, text, sums, eikonal_loss, self.igr_weight, self.mask_weight, self.clip_weight, P)
+        return loss, dict(color=st[1], eikonal=eikonal_loss, mask=st[2], cosine=st[3], cosine_shading=st[4] if self.add_no_texture else None,
                           psnr=psnr, s_val=render_out["s_val"][:1].mean()), images
 
     def clip_loss(self, iter_i, camera=None):

@@ -148,16 +148,28 @@ int avc_render_points_bwd_ring(int net, const float* pts, const float* rays_o, c
  * the full-frame mode); color / extra [R,3], wsum [R], nsum [R,3] = sum_i w_i n_i (NULL: no shading, both images = extra_color);
  * true_rgb [P,3], mask [P] (what the losses use); bg [P] grey background outside the silhouette (NULL: bg_const); light = device
  * [4] (unit light direction, ambience).  Outputs: images [2][P][3] (0 = texture_shading, or extra_color if img0_is_extra; 1 =
- * rand_shading_rgb) and partial [avc_shade_loss_blocks(P)][4] = per-block sums of (|color - true| mask, mask, BCE term, 0), summed by the
- * caller.  The backward takes dimg0 / dimg1 [P,3] (NULL: unused image) and gs = device [2] (d loss / d l1-sum, d loss / d bce-sum) and
- * writes dcolor / dextra [R,3], dwsum [R], dnsum [R,3] for every ray that owns a pixel. */
+ * rand_shading_rgb), partial [avc_shade_loss_blocks(P)][4] = per-block sums of (|color - true| mask, mask, BCE term, (color - true)^2
+ * mask: the logged psnr of main.py:493) and sums [4] = their totals, added up in a fixed order by the block that finishes last
+ * (ticket: one zero-initialised device word per stream of calls; the kernel leaves it zero).  The backward takes dimg0 / dimg1 [P,3] (NULL:
+ * unused image) and gs = device [4], the gradient of `sums` ([0]: d loss / d l1-sum, [2]: d loss / d bce-sum), and writes dcolor / dextra
+ * [R,3], dwsum [R], dnsum [R,3] for every ray that owns a pixel. */
 int avc_shade_loss_blocks(int P);
 int avc_shade_loss_fwd(const float* color, const float* extra, const float* wsum, const float* nsum, const float* true_rgb,
                        const float* mask, const int* ray_of_pixel, const float* bg, float bg_const, const float* light, int P,
-                       int img0_is_extra, float* images, float* partial, void* stream);
+                       int img0_is_extra, float* images, float* partial, float* sums, unsigned* ticket, void* stream);
 int avc_shade_loss_bwd(const float* color, const float* extra, const float* wsum, const float* nsum, const float* true_rgb,
                        const float* mask, const int* ray_of_pixel, const float* light, int P, int img0_is_extra, const float* dimg0,
                        const float* dimg1, const float* gs, float* dcolor, float* dextra, float* dwsum, float* dnsum, void* stream);
+/* The scalar tail of the loss (main.py:491-534) in one launch each way: cos_b = torch.cosine_similarity(torch.mean(enc[b:b+1], 0),
+ * torch.mean(text, 0), dim=0) for the B images (enc [B,512], text [T,512]) and
+ *   loss = sums[0] / (sums[1] + 1e-5) + eikonal * igr_weight + (sums[2] / P) * mask_weight + sum_b (1 - cos_b) * clip_weight
+ * (the reference's order of additions).  loss: device scalar; out [8] = loss, colour loss, mask loss, cos_0, cos_1 (statistics); saved
+ * [4 B + 1]: what the backward needs.  The backward takes g = d L / d loss (device scalar) and writes d_enc [B,512] and dd [8]: [0..3] the
+ * gradient of sums (what avc_shade_loss_bwd takes as gs), [4] that of the eikonal term. */
+int avc_loss_tail_fwd(const float* enc, const float* text, int B, int T, int D, const float* sums, const float* eikonal, float igr_weight,
+                      float mask_weight, float clip_weight, float P, float* loss, float* out, float* saved, void* stream);
+int avc_loss_tail_bwd(const float* g, const float* enc, const float* text, int B, int T, int D, const float* sums, const float* saved,
+                      float igr_weight, float mask_weight, float clip_weight, float P, float* d_enc, float* dd, void* stream);
 /* CLIP's preprocessing (main.py:261-267,510-511: RandomResizedCrop(224, scale=(1,1)) of a square image = bilinear resize,
  * align_corners = False, no antialias; Normalize): images [B,H,W,3] -> out [B,3,224,224] = (resize - mean) / std, and its transpose
  * (dimages is overwritten).  mean / std: HOST arrays of 3 floats. */
@@ -224,6 +236,20 @@ int avc_vit_ln_pack(const float* x, const float* gamma, const float* beta, float
 int avc_vit_linear_packed(const void* xs_packed, const void* w_packed, const float* bias, const float* residual, float* y,
                           void* ys_packed, int M, int N, int K, int act, void* stream);
 int avc_vit_attention_fwd_packed(const float* qkv, void* out_packed, int B, int T, int width, int heads, void* stream);
+/* The per-iteration call of the training loop (main.py:512,524: 1-2 images WITH a gradient to the pixels, M <= 128 rows) hands its
+ * activations over the same way, forward AND backward, on the split-K latency kernel (clip_vit.BlocksFn: the residual blocks of
+ * clip/model.py ResidualAttentionBlock as one autograd node; weights frozen, main.py:260):
+ *   avc_vit_pack          fp32 rows (optionally times QuickGELU'(gelu_pre)) -> packed operand
+ *   avc_vit_linear_small  y = f(xs W^T + b) (+ residual) from a packed operand; act 0 identity, 1 QuickGELU (y_pre receives the
+ *                         pre-activation), 2 times QuickGELU'(gelu_pre[M,N]) (backward of a QuickGELU layer); the result leaves as
+ *                         fp32 rows y and / or as the packed operand ys_packed of the next linear
+ *   avc_vit_ln_bwd        dx = (d LayerNorm(x; gamma) / dx)^T dy (+ residual_grad): fp32 rows and, xs_packed != NULL, the packed
+ *                         operand of the transposed linear behind it (statistics recomputed from x, eps as in avc_vit_ln_pack) */
+int avc_vit_pack(const float* x, const float* gelu_pre, void* xs_packed, int M, int K, void* stream);
+int avc_vit_linear_small(const void* xs_packed, const void* w_packed, const float* bias, const float* residual, const float* gelu_pre,
+                         float* y, float* y_pre, void* ys_packed, int M, int N, int K, int act, void* stream);
+int avc_vit_ln_bwd(const float* dy, const float* x, const float* gamma, float eps, const float* residual_grad, float* dx,
+                   void* xs_packed, int M, int K, void* stream);
 /* multi-head self-attention of ResidualAttentionBlock over T=50 tokens, head dim 64: qkv[B,T,3W] -> out[B,T,W] */
 int avc_vit_attention_fwd(const float* qkv, float* out, int B, int T, int width, int heads, void* stream);
 /* text tower (perceptor.encode_text, main.py:276-288; clip/model.py): self-attention over T <= 128 tokens, head dim 64, with

@@ -55,6 +55,7 @@ def test_fused_glue_equals_the_torch_statement(silhouettes, add_no_texture, text
                     weight_sum=(ro["weight_sum"] + (torch.rand(R, 1, generator=g).to(dev) - 0.5) * 0.6).clamp(-0.05, 1.05),
                     weighted_normals=ro.weighted_normals + torch.randn(R, 3, generator=g).to(dev) * 0.05)
         light = (np.array([0.3, -0.5, 0.8]), 0.13)
+        r.writer = object()          # (makes both statements compute the logged psnr of main.py:493)
         res = []
         for fused in (False, True):
             leaf = {k: v.detach().clone().requires_grad_(True) for k, v in base.items()}
@@ -70,7 +71,7 @@ def test_fused_glue_equals_the_torch_statement(silhouettes, add_no_texture, text
                 img1 = comp["rand_shading_rgb"] if comp["rand_shading_rgb"] is not None else img0
                 images = torch.stack([img0.reshape(-1, 3), img1.reshape(-1, 3)])
             loss.backward()
-            res.append((loss.detach(), {k: v.detach() for k, v in parts.items() if v is not None and k in ("color", "mask", "cosine", "cosine_shading")},
+            res.append((loss.detach(), {k: v.detach() for k, v in parts.items() if v is not None and k in ("color", "mask", "cosine", "cosine_shading", "psnr")},
                         images.detach(), {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()}))
         (la, pa, ia, ga), (lb, pb, ib, gb) = res
         nimg = 2 if add_no_texture else 1
@@ -139,3 +140,44 @@ def test_fused_chess_background_equals_the_torch_statement():
         b = RN.chess_background_fused(H, W, L, sigma, dev)
         assert a.shape == b.shape == (H * W, 1)
         assert (a - b).abs().max() < 2e-6
+
+
+@gpu
+@pytest.mark.parametrize("B,T", [(1, 1), (2, 1), (2, 3)])
+def test_loss_tail_equals_the_torch_statement(B, T):
+    """glue.LossTailFn (cosines + colour / mask normalisation + weighted sum, main.py:491-534) against the same lines in torch: values
+    of the loss and its parts, gradients to the embeddings, the shade-loss sums and the eikonal term."""
+    from avatarclip_amd import glue
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(4 + B + T)
+    enc0 = torch.randn(B, 512, generator=g).to(dev)
+    text = torch.randn(T, 512, generator=g).to(dev)
+    text = text / text.norm(dim=-1, keepdim=True)
+    sums0 = torch.tensor([812.5, 30211.0, 9120.25, 77.0]).to(dev)
+    eik0 = torch.tensor(0.0371).to(dev)
+    w = dict(igr=0.1, mask=0.3, clip=1.7)
+    P = 224.0 * 224.0
+    res = []
+    for fused in (False, True):
+        enc, sums, eik = (t.clone().requires_grad_(True) for t in (enc0, sums0, eik0))
+        if fused:
+            loss, st = glue.LossTailFn.apply(enc, text, sums, eik, w["igr"], w["mask"], w["clip"], P)
+            parts = [st[1], st[2]] + [st[3 + b] for b in range(B)]
+        else:
+            colour = sums[0] / (sums[1] + 1e-5)
+            maskl = sums[2] / P
+            cs = [torch.cosine_similarity(torch.mean(enc[b:b + 1], dim=0), torch.mean(text, dim=0), dim=0) for b in range(B)]
+            loss = colour + eik * w["igr"] + maskl * w["mask"]
+            for c in cs:
+                loss = loss + (1.0 - c) * w["clip"]
+            parts = [colour, maskl] + cs
+        (loss * 1.9).backward()
+        res.append((loss.detach(), [p.detach() for p in parts], enc.grad, sums.grad, eik.grad))
+    (la, pa, ea, sa, ka), (lb, pb, eb, sb, kb) = res
+    assert abs(la.item() - lb.item()) < 2e-6 * abs(la.item())
+    for x, y in zip(pa, pb):
+        assert abs(x.item() - y.item()) < 2e-6 * max(1.0, abs(x.item())), (x.item(), y.item())
+    assert (ea - eb).norm() < 1e-5 * ea.norm()
+    # (sums[1], the mask count, and sums[3], the psnr's squared error, carry no gradient: constants of the iteration)
+    assert torch.allclose(sa[[0, 2]], sb[[0, 2]], rtol=1e-5, atol=1e-12) and sb[1].item() == 0.0 and sb[3].item() == 0.0
+    assert abs(ka.item() - kb.item()) < 1e-6 * abs(ka.item())

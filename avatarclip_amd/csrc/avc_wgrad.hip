@@ -351,3 +351,58 @@ extern "C" int avc_weight_grad_all(const void* fpanels, int ftiles, const void* 
                      bias_partial, out_stride, bias_stride);
   return avc_check_launch("avc_weight_grad_all");
 }
+
+// ---- split sums and the way back to the dense parameter vector (what the caller of avc_weight_grad_all does next) ----
+// acc[j] (+)= sum_s partial[s][j] for the gout_size weight-product floats followed by the gbias_size bias floats, splits added in
+// order (deterministic), 4 floats per thread: ns x 1.7 MB of streaming reads, one launch instead of two torch reductions + two adds
+// per slab.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial, int ns,
+                                                           long stride, long bstride, int gout4, int gbias4, float* __restrict__ acc,
+                                                           int accumulate) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= gout4 + gbias4) return;
+  const f4* src = j < gout4 ? reinterpret_cast<const f4*>(partial) + j : reinterpret_cast<const f4*>(bpartial) + (j - gout4);
+  const long st4 = (j < gout4 ? stride : bstride) >> 2;
+  f4 a = {0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 8 <= ns; s += 8) {
+    f4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + (long)(s + u) * st4);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += v[u];
+  }
+  for (; s < ns; ++s) a += __builtin_nontemporal_load(src + (long)s * st4);
+  f4* out = reinterpret_cast<f4*>(acc) + j;
+  if (accumulate) a += *out;
+  *out = a;
+}
+// grad[t] = sum_{k in [off[t], off[t+1])} acc[src[k]] * scale[k]: the tile layout of the products -> the dense parameter vector (a
+// parameter that several tile entries map to -- the hi + lo slots of the merged last-layer product -- adds them in list order)
+__global__ __launch_bounds__(256) void wgrad_unpack_kernel(const float* __restrict__ acc, const int* __restrict__ off, const int* __restrict__ src,
+                                                           const float* __restrict__ scale, int nparam, float* __restrict__ grad) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= nparam) return;
+  float g = 0.f;
+  for (int k = off[t]; k < off[t + 1]; ++k) g += acc[src[k]] * scale[k];
+  grad[t] = g;
+}
+extern "C" int avc_weight_grad_reduce(const float* partial, const float* bias_partial, int nsplit, int out_stride, int bias_stride,
+                                      int gout_size, int gbias_size, float* acc, int accumulate, void* stream) {
+  if ((gout_size & 3) || (gbias_size & 3) || (out_stride & 3) || (bias_stride & 3)) {
+    avc_set_error("avc_weight_grad_reduce: sizes and strides must be multiples of 4 floats");
+    return 1;
+  }
+  if (nsplit < 1 || !partial || !acc || (gbias_size && !bias_partial)) { avc_set_error("avc_weight_grad_reduce: bad arguments"); return 1; }
+  const int n4 = (gout_size + gbias_size) / 4;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial, bias_partial, nsplit,
+                     (long)out_stride, (long)bias_stride, gout_size / 4, gbias_size / 4, acc, accumulate);
+  return avc_check_launch("avc_weight_grad_reduce");
+}
+extern "C" int avc_weight_grad_unpack(const float* acc, const int* off, const int* src, const float* scale, int nparam, float* grad,
+                                      void* stream) {
+  if (nparam <= 0) return 0;
+  if (!acc || !off || !src || !scale || !grad) { avc_set_error("avc_weight_grad_unpack: NULL buffer"); return 1; }
+  hipLaunchKernelGGL(wgrad_unpack_kernel, dim3((nparam + 255) / 256), dim3(256), 0, (hipStream_t)stream, acc, off, src, scale, nparam, grad);
+  return avc_check_launch("avc_weight_grad_unpack");
+}

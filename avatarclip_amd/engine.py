@@ -31,6 +31,14 @@ class _DevLayout:
         self.un_scale = t(lay.un_scale)
         self.ub_src = t(lay.ub_src)
         self.ub_tgt = t(lay.ub_tgt)
+        # the same maps as a per-parameter list (CSR) over [gout | gbias]: what avc_weight_grad_unpack gathers with
+        tgt = np.concatenate([lay.un_tgt, lay.ub_tgt]).astype(np.int64)
+        src = np.concatenate([lay.un_src, np.asarray(lay.ub_src, np.int64) + lay.gout_size]).astype(np.int64)
+        scl = np.concatenate([lay.un_scale, np.ones(len(lay.ub_tgt), np.float32)]).astype(np.float32)
+        order = np.argsort(tgt, kind="stable")
+        off = np.zeros(lay.nparam + 1, np.int64)
+        np.cumsum(np.bincount(tgt, minlength=lay.nparam), out=off[1:])
+        self.csr_off, self.csr_src, self.csr_scale = t(off.astype(np.int32)), t(src[order].astype(np.int32)), t(scl[order])
         self._offsets_arr = (ctypes.c_int * PK.OFF_COUNT)(*[int(v) for v in lay.offsets])
         self.offsets = ctypes.cast(self._offsets_arr, ctypes.c_void_p)
 
@@ -178,6 +186,7 @@ class Engine:
                                   # 512^2 x 64 spp slab (262144 blocks) has its 256 splits either way; smaller point sets want the finer deal -- at 224^2 (100352
                                   # blocks) 256 splits x 17 pairs instead of 98 x 17 workgroups over 256 CUs: 8.52 -> 8.08 ms (profiles/r03_ab_kernels.txt)
     WG_MAX_SPLITS = int(os.environ.get("AVC_WG_MAX_SPLITS", "256"))   # (<= 256: the size of the split buffers)
+    FUSED_WG_TAIL = os.environ.get("AVC_FUSED_WG_TAIL", "1") != "0"    # split sums + un-packing of the dense gradient as 1 + 1 launches
     MAX_FWD_WAVES = 2048          # persistent grid of avc_render_points_fwd: 256 CUs x one 8-wave workgroup
     MAX_BWD_WAVES = 2048          # 256 CUs x one 8-wave workgroup
     # Operand panels (csrc/avc_mlp.h: PanelLayout).  F region: 89 tiles = 5.6 KiB per point (full nets), written by the training
@@ -449,15 +458,22 @@ class Engine:
         rays_per_chunk, rays_per_slab = self.plan(R, S)
         if rays_per_chunk < R:
             panels_valid = False
-        gout = torch.zeros(lay.gout_size, device=self.device, dtype=torch.float32)
-        gbias = torch.zeros(max(lay.gbias_size, 1), device=self.device, dtype=torch.float32)
+        rg = self._ring_setup() if self.RING else None
+        # the split sums and the way back to the dense vector: one launch per slab + one at the end (avc_weight_grad_reduce / _unpack);
+        # the ring experiment patches columns of the sums, so it keeps the torch statement of the same arithmetic
+        fused_tail = rg is None and self.FUSED_WG_TAIL and lay.gout_size % 4 == 0 and lay.gbias_size % 4 == 0
+        if fused_tail:
+            gacc = torch.empty(lay.gout_size + lay.gbias_size, device=self.device, dtype=torch.float32)
+            nslab = 0
+        else:
+            gout = torch.zeros(lay.gout_size, device=self.device, dtype=torch.float32)
+            gbias = torch.zeros(max(lay.gbias_size, 1), device=self.device, dtype=torch.float32)
         if self._partials is None:
             self._partials = torch.empty(256, lay.gout_size, device=self.device, dtype=torch.float32)
             self._bpartials = torch.empty(256, max(lay.gbias_size, 1), device=self.device, dtype=torch.float32)
         st = L.stream()
         esz = 4
         scratch_out = None
-        rg = self._ring_setup() if self.RING else None
         if rg is not None:
             rg["err"].zero_()
         pairs_host = rg["rest"] if rg is not None else self._pairs_host
@@ -505,6 +521,12 @@ class Engine:
                                                          pairs_host.ctypes.data, nblk, L.ptr(self._partials),
                                                          L.ptr(self._bpartials), ns, self._partials.stride(0),
                                                          self._bpartials.stride(0), st), "avc_weight_grad_all")
+                    if fused_tail:
+                        L.check(self.lib.avc_weight_grad_reduce(L.ptr(self._partials), L.ptr(self._bpartials), ns, self._partials.stride(0),
+                                                                self._bpartials.stride(0), lay.gout_size, lay.gbias_size, L.ptr(gacc),
+                                                                int(nslab > 0), st), "avc_weight_grad_reduce")
+                        nslab += 1
+                        continue
                     po, pb_ = self._partials[:ns].sum(0), self._bpartials[:ns].sum(0)
                     if rg is not None:   # the ring products' columns of the split buffers are not written by this launch (stale): take the consumers' sums
                         for m, (o_off, b_off) in enumerate(rg["offs"]):
@@ -513,10 +535,18 @@ class Engine:
                     gout += po
                     gbias += pb_
         self._panel_owner = None
-        grad = torch.zeros(lay.nparam, device=self.device, dtype=torch.float32)
-        grad.index_add_(0, self.dl.un_tgt, gout[self.dl.un_src] * self.dl.un_scale)
-        if lay.gbias_size:
-            grad.index_add_(0, self.dl.ub_tgt, gbias[self.dl.ub_src])
+        if fused_tail:
+            grad = torch.empty(lay.nparam, device=self.device, dtype=torch.float32)
+            if nslab == 0:
+                grad.zero_()
+            else:
+                L.check(self.lib.avc_weight_grad_unpack(L.ptr(gacc), L.ptr(self.dl.csr_off), L.ptr(self.dl.csr_src), L.ptr(self.dl.csr_scale),
+                                                        lay.nparam, L.ptr(grad), st), "avc_weight_grad_unpack")
+        else:
+            grad = torch.zeros(lay.nparam, device=self.device, dtype=torch.float32)
+            grad.index_add_(0, self.dl.un_tgt, gout[self.dl.un_src] * self.dl.un_scale)
+            if lay.gbias_size:
+                grad.index_add_(0, self.dl.ub_tgt, gbias[self.dl.ub_src])
         # (d loss / d (sdf bias) = sum of d_sdf over all points cancels heavily -- the eikonal term pulls both ways -- and a single bf16
         # slot of d_sdf used to get it wrong by several percent; the tile now carries d_sdf as hi + lo, see packing.py / avc_bwd_body.h.
         # AVC_SDF_BIAS_FP32=1 restores the old override from the fp32 tensor for A/B.)

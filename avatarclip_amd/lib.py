@@ -42,10 +42,12 @@ _SIGS = {
     "avc_vit_attention_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "avc_vit_attention_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "avc_probe_mfma": (c_int, [P, P, P, P, P, P, P]),
-    "avc_rasterize_faces": (c_int, [P, P, c_int, c_int, c_float, c_float, P, P]),
+    "avc_rasterize_faces": (c_int, [P, P, c_int, c_int, c_float, c_float, P, P, P]),
     "avc_dense_params_fwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P]),
     "avc_dense_params_bwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P]),
     "avc_weight_grad_all": (c_int, [P, c_int, P, c_int, c_int, P, c_long, P, P, c_int, c_int, c_int, P]),
+    "avc_weight_grad_reduce": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
+    "avc_weight_grad_unpack": (c_int, [P, P, P, P, c_int, P, P]),
     "avc_shade_loss_blocks": (c_int, [c_int]),
     "avc_shade_loss_fwd": (c_int, [P, P, P, P, P, P, P, P, c_float, P, c_int, c_int, P, P, P, P, P]),
     "avc_loss_tail_fwd": (c_int, [P, P, c_int, c_int, c_int, P, P, c_float, c_float, c_float, c_float, P, P, P, P]),

@@ -52,6 +52,7 @@ class MeshPrior:
         self.light2 = torch.cat([light_ambient + light_directional * c.clamp(min=0),
                                  light_ambient + light_directional * (-c).clamp(min=0)]).contiguous()
         self.lib = L.load()
+        self._zbuf = None
 
     @classmethod
     def from_obj(cls, path, **kw):
@@ -88,8 +89,10 @@ class MeshPrior:
         fz = ndc[self.faces2].reshape(-1, 9).contiguous()
         S2 = 2 * self.image_size                                    # anti_aliasing=True
         img = torch.empty(S2, S2, device=dev, dtype=torch.float32)
-        L.check(self.lib.avc_rasterize_faces(L.ptr(fz), L.ptr(self.light2), fz.shape[0], S2, self.near, self.far, L.ptr(img), L.stream()),
-                "avc_rasterize_faces")
+        if self._zbuf is None or self._zbuf.numel() != S2 * S2:     # (all bits set = empty; every call leaves it that way)
+            self._zbuf = torch.full((S2 * S2,), -1, dtype=torch.int64, device=dev)
+        L.check(self.lib.avc_rasterize_faces(L.ptr(fz), L.ptr(self.light2), fz.shape[0], S2, self.near, self.far, L.ptr(img),
+                                             L.ptr(self._zbuf), L.stream()), "avc_rasterize_faces")
         return torch.nn.functional.avg_pool2d(img[None, None], kernel_size=2, stride=2)[0, 0]
 
     def __call__(self, eye, at):

@@ -118,6 +118,14 @@ int avc_weight_grad_all(const void* fpanels, int ftiles, const void* gpanels, in
                         const int* pairs /* host */, long nblk, float* partial, float* bias_partial, int nsplit,
                         int out_stride, int bias_stride, void* stream);
 
+/* What follows avc_weight_grad_all (the tail of main.py:537's backward for the MLP weights): acc [gout_size + gbias_size] (+)= the sum
+ * over the nsplit slabs of partial / bias_partial, added in split order (accumulate != 0: on top of acc, i.e. the previous slab of
+ * points); then grad[t] = sum_{k = off[t] .. off[t+1]-1} acc[src[k]] * scale[k] maps the products' tile layout back to the dense
+ * parameter vector (device tables built from packing.Layout.un_* / ub_*, engine._DevLayout). */
+int avc_weight_grad_reduce(const float* partial, const float* bias_partial, int nsplit, int out_stride, int bias_stride, int gout_size,
+                           int gbias_size, float* acc, int accumulate, void* stream);
+int avc_weight_grad_unpack(const float* acc, const int* off, const int* src, const float* scale, int nparam, float* grad, void* stream);
+
 /* Role-specialised variant of avc_render_points_bwd (same reference lines: main.py:537 through fields.py:96-107): one persistent
  * launch of `grid` workgroups (one per CU) in which, per XCD, ntypes * cpt CONSUMER workgroups each own the fp32 accumulators of
  * one weight-gradient product abar_m (x) h_in of a middle SDF layer (ntypes = avc_bwd_ring_types(net) products, cpt instances
@@ -267,10 +275,12 @@ int avc_probe_mfma(const void* a_f16, const void* b_f16, float* d, const void* a
  * face per pixel of an image_size x image_size grid (the caller passes the 2x super-sampled size and average-pools,
  * anti_aliasing=True), value = that face's light intensity, 0 = background.
  * faces[F,9]: per face three vertices (x, y in NDC after look + perspective, z = camera depth), the fill_back copies
- * (reversed vertex order) included by the caller; light[F]: ambient + directional intensity per face (lighting.py, world
- * space).  image[image_size, image_size], row 0 = top (rasterize.py's final flip applied). */
+ * (reversed vertex order) included by the caller; light[F]: ambient + directional intensity per face
+ * (lighting.py, world space).  image[image_size, image_size], row 0 = top (rasterize.py's final flip applied).  zbuf: the
+ * z-buffer of 64-bit (depth bits, face index) keys the faces race into with atomicMin -- the caller fills it with 0xFF bytes once;
+ * every call hands it back that way. */
 int avc_rasterize_faces(const float* faces, const float* light, int F, int image_size, float near_, float far_,
-                        float* image, void* stream);
+                        float* image, void* zbuf /* image_size^2 x 8 bytes, all bits set on entry; left so */, void* stream);
 
 #ifdef __cplusplus
 }

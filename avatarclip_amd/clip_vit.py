@@ -154,7 +154,7 @@ class BlocksFn(torch.autograd.Function):
     node: activations go from kernel to kernel as packed bf16 operands, forward and backward -- LayerNorm writes the operand of the
     linear behind it, attention that of the out-projection, c_fc + QuickGELU that of c_proj; in the backward the proj^T product leaves
     already multiplied by QuickGELU' and packed, and the LayerNorm backward adds the residual branch's gradient and packs its result
-    for the transposed linear below.  7 + 9 launches per block instead of 11 + ~14 (a packing launch per linear, torch LayerNorm
+    for the transposed linear below.  7 + 8 launches per block instead of 11 + ~14 (a packing launch per linear, torch LayerNorm
     kernels, AccumulateGrad adds).  Arithmetic as in LinearFn / AttentionFn / F.layer_norm: bf16 operands, fp32 accumulation, fp32
     residual stream and LayerNorm statistics."""
 
@@ -205,7 +205,6 @@ class BlocksFn(torch.autograd.Function):
         p_g2, p_dqkv = model._train_buf("g2", M, W), model._train_buf("dqkv", M, 3 * W)
         t768 = torch.empty(5, M, W, device=dev, dtype=torch.float32)
         dy2, da, dy1, bufa, bufb = t768[0], t768[1], t768[2], t768[3], t768[4]
-        dqkv = torch.empty(M, 3 * W, device=dev, dtype=torch.float32)
         L.check(lib.avc_vit_pack(L.ptr(g), None, L.ptr(p_g), M, W, st), "avc_vit_pack")
         for i in range(len(model.blocks) - 1, -1, -1):
             blk = model.blocks[i]
@@ -220,8 +219,8 @@ class BlocksFn(torch.autograd.Function):
                     "avc_vit_ln_bwd")
             L.check(lib.avc_vit_linear_small(L.ptr(p_g2), L.ptr(blk["out"].wtp), None, None, None, L.ptr(da), None, None,
                                              M, W, W, 0, st), "avc_vit_linear_small")
-            L.check(lib.avc_vit_attention_bwd(L.ptr(qkvs[i]), L.ptr(da), L.ptr(dqkv), B, TOKENS, W, HEADS, st), "avc_vit_attention_bwd")
-            L.check(lib.avc_vit_pack(L.ptr(dqkv), None, L.ptr(p_dqkv), M, 3 * W, st), "avc_vit_pack")
+            L.check(lib.avc_vit_attention_bwd_packed(L.ptr(qkvs[i]), L.ptr(da), L.ptr(p_dqkv), B, TOKENS, W, HEADS, st),
+                    "avc_vit_attention_bwd_packed")
             L.check(lib.avc_vit_linear_small(L.ptr(p_dqkv), L.ptr(blk["qkv"].wtp), None, None, None, L.ptr(dy1), None, None,
                                              M, W, 3 * W, 0, st), "avc_vit_linear_small")
             # ln_1 backward + residual: the gradient of the block's input, packed for the block below

@@ -373,7 +373,7 @@ extern "C" int avc_vit_linear_packed(const void* xs_packed, const void* w_packed
 
 // ---- the per-iteration training pipeline (1-2 images WITH a gradient to the pixels, M <= 128 rows): the same packed hand-offs for
 // the latency kernel, forward and backward (clip_vit.BlocksFn).  Per block 7 launches forward (ln_pack, qkv, attention, out +
-// residual, ln_pack, fc -> pre + packed QuickGELU, proj + residual) and 9 backward instead of 11 + 14 torch-autograd nodes with a
+// residual, ln_pack, fc -> pre + packed QuickGELU, proj + residual) and 8 backward instead of 11 + 14 torch-autograd nodes with a
 // packing launch in front of every linear, torch LayerNorm kernels and AccumulateGrad adds between them.
 extern "C" int avc_vit_pack(const float* x, const float* gelu_pre, void* xs_packed, int M, int K, void* stream) {
   if (M <= 0) return 0;
@@ -647,6 +647,12 @@ __global__ __launch_bounds__(64 * AT_PARTS) void vit_attn_bwd_kernel(const float
 int avc_attn_fwd_mfma(const float* qkv, float* out, int B, int width, int heads, void* stream);
 int avc_attn_bwd_mfma(const float* qkv, const float* dout, float* dqkv, int B, int width, int heads, void* stream);
 int avc_attn_fwd_mfma_packed(const float* qkv, void* out_packed, int B, int width, int heads, void* stream);
+int avc_attn_bwd_mfma_packed(const float* qkv, const float* dout, void* dqkv_packed, int B, int width, int heads, void* stream);
+extern "C" int avc_vit_attention_bwd_packed(const float* qkv, const float* dout, void* dqkv_packed, int B, int T, int width, int heads,
+                                            void* stream) {
+  if (T != AT_T || width != heads * AT_D) { avc_set_error("avc_vit_attention: built for 50 tokens, head dim 64"); return 1; }
+  return avc_attn_bwd_mfma_packed(qkv, dout, dqkv_packed, B, width, heads, stream);
+}
 extern "C" int avc_vit_attention_fwd_packed(const float* qkv, void* out_packed, int B, int T, int width, int heads, void* stream) {
   if (T != AT_T || width != heads * AT_D) { avc_set_error("avc_vit_attention: built for 50 tokens, head dim 64"); return 1; }
   return avc_attn_fwd_mfma_packed(qkv, out_packed, B, width, heads, stream);

@@ -162,6 +162,12 @@ __global__ __launch_bounds__(256) void vit_attn_fwd_mfma_kernel(const float* __r
   }
 }
 
+// PACKED: dqkv leaves as the packed bf16 operand of the transposed in-projection (K = 3 W; element (row, col) = slot col & 7 of lane
+// (row & 31, (col >> 3) & 1) of k-step col >> 4 of row tile row >> 5) instead of fp32 rows: the per-iteration training pipeline
+__device__ __forceinline__ void put_packed_elem(bf* xs, int KS, long row, int col, float v) {
+  xs[(((row >> 5) * KS + (col >> 4)) * 64 + (row & 31) + 32 * ((col >> 3) & 1)) * 8 + (col & 7)] = (bf)v;
+}
+template <bool PACKED>
 __global__ __launch_bounds__(256) void vit_attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                 float* __restrict__ dqkv, int Wd, int heads, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -217,9 +223,15 @@ __global__ __launch_bounds__(256) void vit_attn_bwd_mfma_kernel(const float* __r
 #pragma unroll
       for (int s = 0; s < 4; ++s) o = MF<b8>::mma(frag_perm(m.KT, 32 * td + n, s, h), dsf[s], o);
       if (i < ATM_T) {
-        float* qp = dqkv + ((long)b * ATM_T + i) * 3 * Wd + hd * ATM_D + 32 * td;
+        if (PACKED) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) qp[acc_row(r, h)] = o[r];
+          for (int r = 0; r < 16; ++r)
+            put_packed_elem(reinterpret_cast<bf*>(dqkv), (3 * Wd) >> 4, (long)b * ATM_T + i, hd * ATM_D + 32 * td + acc_row(r, h), o[r]);
+        } else {
+          float* qp = dqkv + ((long)b * ATM_T + i) * 3 * Wd + hd * ATM_D + 32 * td;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) qp[acc_row(r, h)] = o[r];
+        }
       }
     }
     // P^T and dS^T to LDS as [key][query] for the products that contract over the queries
@@ -248,9 +260,15 @@ __global__ __launch_bounds__(256) void vit_attn_bwd_mfma_kernel(const float* __r
   for (int r = 0; r < 16; ++r) {
     const int j = 32 * tj + acc_row(r, h);
     if (j < ATM_T) {
-      float* kp = dqkv + ((long)b * ATM_T + j) * 3 * Wd + hd * ATM_D + 32 * td + n;
-      kp[Wd] = dk[r];
-      kp[2 * Wd] = dv[r];
+      if (PACKED) {
+        const int col = hd * ATM_D + 32 * td + n;
+        put_packed_elem(reinterpret_cast<bf*>(dqkv), (3 * Wd) >> 4, (long)b * ATM_T + j, Wd + col, dk[r]);
+        put_packed_elem(reinterpret_cast<bf*>(dqkv), (3 * Wd) >> 4, (long)b * ATM_T + j, 2 * Wd + col, dv[r]);
+      } else {
+        float* kp = dqkv + ((long)b * ATM_T + j) * 3 * Wd + hd * ATM_D + 32 * td + n;
+        kp[Wd] = dk[r];
+        kp[2 * Wd] = dv[r];
+      }
     }
   }
 }
@@ -268,7 +286,16 @@ int avc_attn_bwd_mfma(const float* qkv, const float* dout, float* dqkv, int B, i
   const int lds = (int)sizeof(AtmMatsBwd);
   static unsigned long long attr_seen = 0;
   if (avc_first_use_on_device(attr_seen))
-    (void)hipFuncSetAttribute((const void*)vit_attn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL(vit_attn_bwd_mfma_kernel, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, qkv, dout, dqkv, width, heads, 0.125f);
+    (void)hipFuncSetAttribute((const void*)vit_attn_bwd_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(vit_attn_bwd_mfma_kernel<false>, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, qkv, dout, dqkv, width, heads, 0.125f);
   return avc_check_launch("avc_vit_attention_bwd");
+}
+int avc_attn_bwd_mfma_packed(const float* qkv, const float* dout, void* dqkv_packed, int B, int width, int heads, void* stream) {
+  const int lds = (int)sizeof(AtmMatsBwd);
+  static unsigned long long attr_seen = 0;
+  if (avc_first_use_on_device(attr_seen))
+    (void)hipFuncSetAttribute((const void*)vit_attn_bwd_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(vit_attn_bwd_mfma_kernel<true>, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, qkv, dout, (float*)dqkv_packed, width,
+                     heads, 0.125f);
+  return avc_check_launch("avc_vit_attention_bwd_packed");
 }

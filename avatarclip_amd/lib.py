@@ -36,6 +36,7 @@ _SIGS = {
     "avc_vit_ln_pack": (c_int, [P, P, P, c_float, c_int, c_int, P, P]),
     "avc_vit_linear_packed": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "avc_vit_pack": (c_int, [P, P, P, c_int, c_int, P]),
+    "avc_vit_attention_bwd_packed": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "avc_vit_linear_small": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "avc_vit_ln_bwd": (c_int, [P, P, P, c_float, P, P, P, c_int, c_int, P]),
     "avc_vit_attention_fwd_packed": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),

@@ -254,6 +254,8 @@ int avc_vit_attention_fwd_packed(const float* qkv, void* out_packed, int B, int 
  *   avc_vit_ln_bwd        dx = (d LayerNorm(x; gamma) / dx)^T dy (+ residual_grad): fp32 rows and, xs_packed != NULL, the packed
  *                         operand of the transposed linear behind it (statistics recomputed from x, eps as in avc_vit_ln_pack) */
 int avc_vit_pack(const float* x, const float* gelu_pre, void* xs_packed, int M, int K, void* stream);
+/* avc_vit_attention_bwd with dqkv leaving as the packed operand ([B * 50, 3 W]) of the transposed in-projection */
+int avc_vit_attention_bwd_packed(const float* qkv, const float* dout, void* dqkv_packed, int B, int T, int width, int heads, void* stream);
 int avc_vit_linear_small(const void* xs_packed, const void* w_packed, const float* bias, const float* residual, const float* gelu_pre,
                          float* y, float* y_pre, void* ys_packed, int M, int N, int K, int act, void* stream);
 int avc_vit_ln_bwd(const float* dy, const float* x, const float* gamma, float eps, const float* residual_grad, float* dx,

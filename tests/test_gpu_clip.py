@@ -203,6 +203,19 @@ def test_layernorm_backward_and_packed_epilogues_of_the_training_pipeline():
         L.check(lib.avc_vit_pack(L.ptr(y), L.ptr(pre), L.ptr(py_ref), M, 3072, L.stream()), "pack")
         assert torch.equal(py[:used2], py_ref[:used2])
     assert lib.avc_vit_linear_small(L.ptr(ps), L.ptr(lin.wp), None, None, None, None, None, None, 100, 3072, 768, 0, L.stream()) != 0
+    # attention backward with its result packed for the transposed in-projection == packing of its fp32 result
+    for B in (1, 2):
+        M = 50 * B
+        qkv = torch.randn(B, 50, 2304, generator=g).to(dev)
+        do = torch.randn(B, 50, 768, generator=g).to(dev)
+        dq = torch.empty_like(qkv)
+        nb3 = lib.avc_vit_workspace_bytes(M, 2304)
+        pa, pb = torch.zeros(nb3, dtype=torch.uint8, device=dev), torch.zeros(nb3, dtype=torch.uint8, device=dev)
+        L.check(lib.avc_vit_attention_bwd(L.ptr(qkv), L.ptr(do), L.ptr(dq), B, 50, 768, 12, L.stream()), "attention_bwd")
+        L.check(lib.avc_vit_pack(L.ptr(dq), None, L.ptr(pa), M, 2304, L.stream()), "pack")
+        L.check(lib.avc_vit_attention_bwd_packed(L.ptr(qkv), L.ptr(do), L.ptr(pb), B, 50, 768, 12, L.stream()), "attention_bwd_packed")
+        used3 = ((M + 31) // 32) * 144 * 1024
+        assert torch.equal(pa[:used3], pb[:used3])
 
 
 @gpu

@@ -69,3 +69,26 @@ def test_emulated_wave_matches_analytic(name, spec):
         err = np.abs(a - b_).max() / (np.abs(b_).max() + 1e-30)
         assert err < 1e-6, (pname, err)
         off += n_
+
+
+def test_unpack_tables_as_per_parameter_lists_equal_the_scatter_statement():
+    """engine._DevLayout.csr_* (what avc_weight_grad_unpack gathers with) against the index_add statement of the same map
+    (packing.Layout.un_* / ub_*): every dense parameter receives exactly the tile entries that scatter into it, with their scales."""
+    import numpy as np
+    import torch
+    from avatarclip_amd import packing as PK
+    from avatarclip_amd.engine import _DevLayout
+    for spec in (PK.NetSpec(128, 2, 1), PK.NetSpec(256, 2, 1)):
+        lay = PK.layout_for(spec)
+        dl = _DevLayout(lay, "cpu")
+        rng = np.random.default_rng(3)
+        acc = torch.from_numpy(rng.standard_normal(lay.gout_size + lay.gbias_size))
+        ref = torch.zeros(lay.nparam, dtype=torch.float64)
+        ref.index_add_(0, torch.from_numpy(lay.un_tgt), acc[torch.from_numpy(lay.un_src)] * torch.from_numpy(lay.un_scale).double())
+        ref.index_add_(0, torch.from_numpy(np.asarray(lay.ub_tgt, np.int64)), acc[lay.gout_size + torch.from_numpy(np.asarray(lay.ub_src, np.int64))])
+        off, src, scl = dl.csr_off.long(), dl.csr_src.long(), dl.csr_scale.double()
+        assert off[0] == 0 and off[-1] == len(src) == len(lay.un_src) + len(lay.ub_src)
+        seg = torch.repeat_interleave(torch.arange(lay.nparam), off[1:] - off[:-1])
+        got = torch.zeros(lay.nparam, dtype=torch.float64).index_add_(0, seg, acc[src] * scl)
+        assert torch.allclose(got, ref, rtol=0, atol=1e-12)
+        assert int((off[1:] - off[:-1]).min()) >= 1          # every parameter of the two networks has a source

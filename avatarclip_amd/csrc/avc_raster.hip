@@ -10,7 +10,10 @@
 // = pixels, so a large face is 64-wide too), evaluates the edge functions and the depth exactly as above and does ONE
 // atomicMin(zbuf[pixel], depth_bits << 32 | face) per covered pixel -- depths are positive floats (near < z), so the integer order
 // of the key is (depth, face index): nearest face, ties to the lower index, independent of the order the atomics arrive in.  A
-// second launch turns the keys into the faces' light values and puts the all-ones "empty" key back.  (The first version of this
+// second launch turns the keys into the faces' light values and puts the all-ones "empty" key back.  A face whose box holds more than
+// RS_LARGE pixels (a close-up, a face cut by the near plane: one wavefront would walk up to the whole image) is only listed; a
+// tile-parallel launch in between gives every 16 x 16 pixel tile a scan over that (short) list -- the first version's scheme, which
+// is the right one for exactly those faces.  (The first version of this
 // file gave every 16 x 16 pixel tile a scan over ALL faces with an LDS survivor list: 0.37 ms for the 27 552 faces of the prior at
 // 512^2, bound by the few tiles over the head and the hands where a thousand small faces survive the box test; staging the faces
 // through LDS or scanning 1 024 per round did not move that.  profiles/r04_ab_kernels.txt)
@@ -20,53 +23,110 @@
 #pragma clang fp contract(off)   // same roundings as the fp32 restatement (edge tests are sign tests)
 
 #define RS_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define RS_LARGE 1024     // pixels in a face's box from which it goes to the tile-parallel pass
+#define RS_TILE 16
 
+// depth of face (x0..z2) at pixel (xi, yi), or a negative number if the pixel centre is outside / the depth out of range
+struct FaceEq {
+  float x0, y0, z0, x1, y1, z1, x2, y2, z2;
+  float p0x, p0y, p1x, p1y, p2x, p2y, den;
+};
+__device__ __forceinline__ bool face_setup(const float* __restrict__ f, int is, FaceEq& e) {
+  e.x0 = f[0]; e.y0 = f[1]; e.z0 = f[2]; e.x1 = f[3]; e.y1 = f[4]; e.z1 = f[5]; e.x2 = f[6]; e.y2 = f[7]; e.z2 = f[8];
+  if ((e.y2 - e.y0) * (e.x1 - e.x0) < (e.y1 - e.y0) * (e.x2 - e.x0)) return false;          // back-facing
+  // pixel-space vertices and the inverse of their homogeneous matrix (rasterize_cuda_kernel.cu, kernel 1)
+  e.p0x = 0.5f * (e.x0 * is + is - 1); e.p0y = 0.5f * (e.y0 * is + is - 1);
+  e.p1x = 0.5f * (e.x1 * is + is - 1); e.p1y = 0.5f * (e.y1 * is + is - 1);
+  e.p2x = 0.5f * (e.x2 * is + is - 1); e.p2y = 0.5f * (e.y2 * is + is - 1);
+  e.den = e.p2x * (e.p0y - e.p1y) + e.p0x * (e.p1y - e.p2y) + e.p1x * (e.p2y - e.p0y);
+  return e.den != 0.f;
+}
+__device__ __forceinline__ float face_depth(const FaceEq& e, int xi, int yi, int is, float near, float far) {
+  const float xp = (2.f * xi + 1.f - is) / is;
+  const float yp = (2.f * yi + 1.f - is) / is;
+  if (((yp - e.y0) * (e.x1 - e.x0) < (xp - e.x0) * (e.y1 - e.y0)) || ((yp - e.y1) * (e.x2 - e.x1) < (xp - e.x1) * (e.y2 - e.y1)) ||
+      ((yp - e.y2) * (e.x0 - e.x2) < (xp - e.x2) * (e.y0 - e.y2)))
+    return -1.f;
+  float w0 = ((e.p1y - e.p2y) * xi + (e.p2x - e.p1x) * yi + (e.p1x * e.p2y - e.p2x * e.p1y)) / e.den;
+  float w1 = ((e.p2y - e.p0y) * xi + (e.p0x - e.p2x) * yi + (e.p2x * e.p0y - e.p0x * e.p2y)) / e.den;
+  float w2 = ((e.p0y - e.p1y) * xi + (e.p1x - e.p0x) * yi + (e.p0x * e.p1y - e.p1x * e.p0y)) / e.den;
+  w0 = fminf(fmaxf(w0, 0.f), 1.f); w1 = fminf(fmaxf(w1, 0.f), 1.f); w2 = fminf(fmaxf(w2, 0.f), 1.f);
+  const float ws = fmaxf(w0 + w1 + w2, 1e-10f);
+  const float zp = 1.f / ((w0 / e.z0 + w1 / e.z1 + w2 / e.z2) / ws);
+  return (zp > near && zp < far) ? zp : -1.f;        // (zp > near >= 0: its bit pattern orders like its value)
+}
+// the face's box in pixel indices, one pixel of slack each way (the edge functions decide); false: off screen (or NaN)
+__device__ __forceinline__ bool face_box(const FaceEq& e, int is, int& xa, int& xb, int& ya, int& yb) {
+  const float xl = fminf(e.x0, fminf(e.x1, e.x2)), xh = fmaxf(e.x0, fmaxf(e.x1, e.x2));
+  const float yl = fminf(e.y0, fminf(e.y1, e.y2)), yh = fmaxf(e.y0, fmaxf(e.y1, e.y2));
+  if (!(xh >= -1.f && xl <= 1.f && yh >= -1.f && yl <= 1.f)) return false;
+  // (clamped in float first: a vertex near the camera plane projects to 1e30, which no int holds)
+  xa = max(0, (int)floorf(fmaxf(0.5f * (xl * is + is - 1), -1.f)) - 1); xb = min(is - 1, (int)ceilf(fminf(0.5f * (xh * is + is - 1), (float)is)) + 1);
+  ya = max(0, (int)floorf(fmaxf(0.5f * (yl * is + is - 1), -1.f)) - 1); yb = min(is - 1, (int)ceilf(fminf(0.5f * (yh * is + is - 1), (float)is)) + 1);
+  return xb >= xa && yb >= ya;
+}
+
+// `large` = [count - 1 (0xFFFFFFFF = none), face indices ...]
 __global__ __launch_bounds__(256) void raster_faces_kernel(const float* __restrict__ faces /* [F,9] x,y (NDC), z (depth) */, int F, int is,
-                                                           float near, float far, unsigned long long* __restrict__ zbuf /* [is,is], y up */) {
+                                                           float near, float far, unsigned long long* __restrict__ zbuf /* [is,is], y up */,
+                                                           unsigned* __restrict__ large) {
   const int fn = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (fn >= F) return;
   float f[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) f[k] = faces[(long)fn * 9 + k];
-  const float x0 = f[0], y0 = f[1], z0 = f[2], x1 = f[3], y1 = f[4], z1 = f[5], x2 = f[6], y2 = f[7], z2 = f[8];
-  if ((y2 - y0) * (x1 - x0) < (y1 - y0) * (x2 - x0)) return;          // back-facing
-  const float xl = fminf(x0, fminf(x1, x2)), xh = fmaxf(x0, fmaxf(x1, x2));
-  const float yl = fminf(y0, fminf(y1, y2)), yh = fmaxf(y0, fmaxf(y1, y2));
-  if (!(xh >= -1.f && xl <= 1.f && yh >= -1.f && yl <= 1.f)) return;  // off screen (or NaN)
-  // pixel-space vertices and the inverse of their homogeneous matrix (rasterize_cuda_kernel.cu, kernel 1)
-  const float p0x = 0.5f * (x0 * is + is - 1), p0y = 0.5f * (y0 * is + is - 1);
-  const float p1x = 0.5f * (x1 * is + is - 1), p1y = 0.5f * (y1 * is + is - 1);
-  const float p2x = 0.5f * (x2 * is + is - 1), p2y = 0.5f * (y2 * is + is - 1);
-  const float den = p2x * (p0y - p1y) + p0x * (p1y - p2y) + p1x * (p2y - p0y);
-  if (den == 0.f) return;
-  // pixels whose centres can lie inside: the box in pixel coordinates, one pixel of slack each way (the edge functions decide)
-  const int xa = max(0, (int)floorf(0.5f * (xl * is + is - 1)) - 1), xb = min(is - 1, (int)ceilf(0.5f * (xh * is + is - 1)) + 1);
-  const int ya = max(0, (int)floorf(0.5f * (yl * is + is - 1)) - 1), yb = min(is - 1, (int)ceilf(0.5f * (yh * is + is - 1)) + 1);
+  FaceEq e;
+  if (!face_setup(f, is, e)) return;
+  int xa, xb, ya, yb;
+  if (!face_box(e, is, xa, xb, ya, yb)) return;
   const int w = xb - xa + 1, h = yb - ya + 1;
-  if (w <= 0 || h <= 0) return;
-  const long n = (long)w * h;
-  for (long idx = lane; idx < n; idx += 64) {
-    const int xi = xa + (int)(idx % w), yi = ya + (int)(idx / w);
-    const float xp = (2.f * xi + 1.f - is) / is;
-    const float yp = (2.f * yi + 1.f - is) / is;
-    if (((yp - y0) * (x1 - x0) < (xp - x0) * (y1 - y0)) || ((yp - y1) * (x2 - x1) < (xp - x1) * (y2 - y1)) ||
-        ((yp - y2) * (x0 - x2) < (xp - x2) * (y0 - y2)))
-      continue;
-    float w0 = ((p1y - p2y) * xi + (p2x - p1x) * yi + (p1x * p2y - p2x * p1y)) / den;
-    float w1 = ((p2y - p0y) * xi + (p0x - p2x) * yi + (p2x * p0y - p0x * p2y)) / den;
-    float w2 = ((p0y - p1y) * xi + (p1x - p0x) * yi + (p0x * p1y - p1x * p0y)) / den;
-    w0 = fminf(fmaxf(w0, 0.f), 1.f); w1 = fminf(fmaxf(w1, 0.f), 1.f); w2 = fminf(fmaxf(w2, 0.f), 1.f);
-    const float ws = fmaxf(w0 + w1 + w2, 1e-10f);
-    const float zp = 1.f / ((w0 / z0 + w1 / z1 + w2 / z2) / ws);
-    if (!(zp > near && zp < far)) continue;        // (zp > near >= 0: its bit pattern orders like its value)
-    const unsigned long long key = ((unsigned long long)__float_as_uint(zp) << 32) | (unsigned)fn;
-    atomicMin(&zbuf[(long)yi * is + xi], key);
+  const int n = w * h;
+  if (n > RS_LARGE) {
+    if (lane == 0) large[1 + (atomicAdd(&large[0], 1u) + 1u)] = (unsigned)fn;
+    return;
+  }
+  for (int idx = lane; idx < n; idx += 64) {
+    const int xi = xa + idx % w, yi = ya + idx / w;
+    const float zp = face_depth(e, xi, yi, is, near, far);
+    if (zp < 0.f) continue;
+    atomicMin(&zbuf[(long)yi * is + xi], ((unsigned long long)__float_as_uint(zp) << 32) | (unsigned)fn);
   }
 }
-// image = light of the winning face (0: background), rows flipped (rasterize.py: y up -> row 0 = top); the z-buffer is left empty
+// the listed large faces, tile-parallel: thread = pixel of a 16 x 16 tile, every face of the list whose box meets the tile is
+// evaluated at the tile's pixels; the running minimum joins the key the small faces left (plain read-modify-write: one thread per pixel)
+__global__ __launch_bounds__(256) void raster_large_kernel(const float* __restrict__ faces, int is, float near, float far,
+                                                           unsigned long long* __restrict__ zbuf, const unsigned* __restrict__ large) {
+  const unsigned nl = large[0] + 1u;
+  if (nl == 0u) return;
+  const int tx0 = blockIdx.x * RS_TILE, ty0 = blockIdx.y * RS_TILE;
+  const int xi = tx0 + (threadIdx.x & 15), yi = ty0 + (threadIdx.x >> 4);
+  unsigned long long best = RS_EMPTY;
+  for (unsigned q = 0; q < nl; ++q) {
+    const int fn = (int)large[1 + q];
+    float f[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) f[k] = faces[(long)fn * 9 + k];
+    FaceEq e;
+    if (!face_setup(f, is, e)) continue;
+    int xa, xb, ya, yb;
+    if (!face_box(e, is, xa, xb, ya, yb)) continue;
+    if (xb < tx0 || xa > tx0 + RS_TILE - 1 || yb < ty0 || ya > ty0 + RS_TILE - 1) continue;     // (uniform over the workgroup)
+    if (xi >= is || yi >= is) continue;
+    const float zp = face_depth(e, xi, yi, is, near, far);
+    if (zp < 0.f) continue;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(zp) << 32) | (unsigned)fn;
+    best = key < best ? key : best;
+  }
+  if (xi < is && yi < is && best != RS_EMPTY) {
+    unsigned long long* z = &zbuf[(long)yi * is + xi];
+    if (best < *z) *z = best;
+  }
+}
+// image = light of the winning face (0: background), rows flipped (rasterize.py: y up -> row 0 = top); the scratch is left empty
 __global__ __launch_bounds__(256) void raster_resolve_kernel(unsigned long long* __restrict__ zbuf, const float* __restrict__ light, int is,
-                                                             float* __restrict__ image) {
+                                                             float* __restrict__ image, unsigned* __restrict__ large) {
   const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p == 0) large[0] = 0xFFFFFFFFu;
   if (p >= is * is) return;
   const unsigned long long key = zbuf[p];
   const int yi = p / is, xi = p % is;
@@ -74,14 +134,22 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(unsigned long long*
   zbuf[p] = RS_EMPTY;
 }
 
+extern "C" long avc_rasterize_scratch_bytes(int F, int image_size) {
+  return (long)image_size * image_size * 8 + ((long)F + 2) * 4;
+}
 extern "C" int avc_rasterize_faces(const float* faces, const float* light, int F, int image_size, float near, float far,
-                                   float* image, void* zbuf, void* stream) {
+                                   float* image, void* scratch, void* stream) {
   if (image_size <= 0) { avc_set_error("avc_rasterize_faces: image_size <= 0"); return 1; }
   if (F < 0 || near < 0.f) { avc_set_error("avc_rasterize_faces: F < 0 or near < 0"); return 1; }
-  if (!image || !zbuf || (F && (!faces || !light))) { avc_set_error("avc_rasterize_faces: NULL buffer"); return 1; }
+  if (!image || !scratch || (F && (!faces || !light))) { avc_set_error("avc_rasterize_faces: NULL buffer"); return 1; }
   hipStream_t s = (hipStream_t)stream;
-  if (F) hipLaunchKernelGGL(raster_faces_kernel, dim3((F + 3) / 4), dim3(256), 0, s, faces, F, image_size, near, far, (unsigned long long*)zbuf);
-  hipLaunchKernelGGL(raster_resolve_kernel, dim3((image_size * image_size + 255) / 256), dim3(256), 0, s, (unsigned long long*)zbuf, light,
-                     image_size, image);
+  unsigned long long* zbuf = (unsigned long long*)scratch;
+  unsigned* large = (unsigned*)(zbuf + (long)image_size * image_size);
+  if (F) {
+    hipLaunchKernelGGL(raster_faces_kernel, dim3((F + 3) / 4), dim3(256), 0, s, faces, F, image_size, near, far, zbuf, large);
+    const int nt = (image_size + RS_TILE - 1) / RS_TILE;
+    hipLaunchKernelGGL(raster_large_kernel, dim3(nt, nt), dim3(256), 0, s, faces, image_size, near, far, zbuf, large);
+  }
+  hipLaunchKernelGGL(raster_resolve_kernel, dim3((image_size * image_size + 255) / 256), dim3(256), 0, s, zbuf, light, image_size, image, large);
   return avc_check_launch("avc_rasterize_faces");
 }

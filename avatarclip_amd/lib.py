@@ -44,6 +44,7 @@ _SIGS = {
     "avc_vit_attention_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "avc_probe_mfma": (c_int, [P, P, P, P, P, P, P]),
     "avc_rasterize_faces": (c_int, [P, P, c_int, c_int, c_float, c_float, P, P, P]),
+    "avc_rasterize_scratch_bytes": (c_long, [c_int, c_int]),
     "avc_dense_params_fwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P]),
     "avc_dense_params_bwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P]),
     "avc_weight_grad_all": (c_int, [P, c_int, P, c_int, c_int, P, c_long, P, P, c_int, c_int, c_int, P]),

@@ -89,8 +89,9 @@ class MeshPrior:
         fz = ndc[self.faces2].reshape(-1, 9).contiguous()
         S2 = 2 * self.image_size                                    # anti_aliasing=True
         img = torch.empty(S2, S2, device=dev, dtype=torch.float32)
-        if self._zbuf is None or self._zbuf.numel() != S2 * S2:     # (all bits set = empty; every call leaves it that way)
-            self._zbuf = torch.full((S2 * S2,), -1, dtype=torch.int64, device=dev)
+        need = self.lib.avc_rasterize_scratch_bytes(fz.shape[0], S2)
+        if self._zbuf is None or self._zbuf.numel() != need:        # (all bits set = empty; every call leaves it that way)
+            self._zbuf = torch.full((need,), 255, dtype=torch.uint8, device=dev)
         L.check(self.lib.avc_rasterize_faces(L.ptr(fz), L.ptr(self.light2), fz.shape[0], S2, self.near, self.far, L.ptr(img),
                                              L.ptr(self._zbuf), L.stream()), "avc_rasterize_faces")
         return torch.nn.functional.avg_pool2d(img[None, None], kernel_size=2, stride=2)[0, 0]

@@ -278,11 +278,13 @@ int avc_probe_mfma(const void* a_f16, const void* b_f16, float* d, const void* a
  * anti_aliasing=True), value = that face's light intensity, 0 = background.
  * faces[F,9]: per face three vertices (x, y in NDC after look + perspective, z = camera depth), the fill_back copies
  * (reversed vertex order) included by the caller; light[F]: ambient + directional intensity per face
- * (lighting.py, world space).  image[image_size, image_size], row 0 = top (rasterize.py's final flip applied).  zbuf: the
- * z-buffer of 64-bit (depth bits, face index) keys the faces race into with atomicMin -- the caller fills it with 0xFF bytes once;
- * every call hands it back that way. */
+ * (lighting.py, world space).  image[image_size, image_size], row 0 = top (rasterize.py's final flip applied).  scratch: the
+ * z-buffer of 64-bit (depth bits, face index) keys the faces race into with atomicMin + the list of the faces too large for that
+ * (handled tile by tile) -- avc_rasterize_scratch_bytes(F, image_size) bytes that the caller fills with 0xFF once; every call hands
+ * them back that way. */
+long avc_rasterize_scratch_bytes(int F, int image_size);
 int avc_rasterize_faces(const float* faces, const float* light, int F, int image_size, float near_, float far_,
-                        float* image, void* zbuf /* image_size^2 x 8 bytes, all bits set on entry; left so */, void* stream);
+                        float* image, void* scratch /* avc_rasterize_scratch_bytes, 0xFF-filled on entry; left so */, void* stream);
 
 #ifdef __cplusplus
 }

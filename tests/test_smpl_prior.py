@@ -71,7 +71,10 @@ def test_hip_rasteriser_matches_restatement():
     V, Fc = z["mesh_v"], z["mesh_f"]
     prior = MeshPrior(V, Fc, device="cuda")
     cams = [(np.array([0.2, 0.3, 1.6]), np.array([0.0, -0.1, 0.05])), (np.array([-1.3, -0.4, -0.9]), np.array([0.05, 0.1, 0.0])),
-            (np.array([0.05, 1.5, 0.6]), np.array([0.0, 0.2, 0.0]))]
+            (np.array([0.05, 1.5, 0.6]), np.array([0.0, 0.2, 0.0])),
+            # close-ups: faces whose boxes hold thousands of sub-pixels (the tile-parallel pass of the rasteriser), the second one
+            # from so near that part of the body is beside / behind the camera
+            (np.array([0.05, 0.35, 0.55]), np.array([0.0, 0.3, 0.0])), (np.array([0.1, 0.0, 0.22]), np.array([0.0, 0.1, 0.0]))]
     for eye, at in cams:
         out = prior(eye, at).cpu().numpy()
         ref = NR.render_one_batch(V.astype(np.float64), Fc, eye, at).astype(np.float32)

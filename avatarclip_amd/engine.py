@@ -274,8 +274,14 @@ class Engine:
 
     def _grow(self, attr, nbytes, dtype=torch.uint8):
         buf = getattr(self, attr)
-        n = nbytes // torch.empty(0, dtype=dtype).element_size()
+        esz = torch.empty(0, dtype=dtype).element_size()
+        n = nbytes // esz
         if buf is None or buf.numel() < n:
+            # whole 2-MiB units: the caching allocator rounds a large request up to that and keeps the rest of the segment as a free block
+            # -- the next 1-2 MB tensor anybody allocates (a long-lived workspace, say) lands in it and pins the whole multi-GiB segment
+            # in torch's cache after this buffer is gone (seen as 89 GiB "reserved" after the 512^2 runner of bench.py was dropped: the
+            # 128-spp leg then planned with 70 GiB less and cut its ray set into chunks)
+            n = ((n * esz + (1 << 21) - 1) >> 21 << 21) // esz
             buf = None                   # release the old buffer BEFORE the larger one is allocated (peak = need, not have + need):
             setattr(self, attr, None)    # neither the attribute nor this local may keep it alive across empty_cache()
             torch.cuda.empty_cache()

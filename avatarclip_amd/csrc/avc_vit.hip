@@ -50,7 +50,10 @@ __global__ __launch_bounds__(64) void vit_pack_x_kernel(const float* __restrict_
 // ways), ONE barrier, then the 16 MT accumulator rows are dealt to the 8 waves: each sums the 8 partials of its rows in a fixed
 // order (deterministic) and runs the epilogue (bias, QuickGELU, residual, store) for them -- a tree reduction with the whole
 // epilogue on wave 0 cost three barrier pairs and 64 serial load / store pairs on one wave.
-template <int MT>
+// NB = k-steps a wave loads as ONE batch before their MFMAs: the per-iteration calls leave most of the chip idle (96-384 workgroups),
+// so the only way to shorten a K = 3072 linear (24 k-steps per wave) is to have all of its loads in flight at once instead of four
+// rounds of six -- 14.7 -> see profiles/r04_ab_kernels.txt
+template <int MT, int NB = 6>
 __global__ __launch_bounds__(64 * VIT_WAVES) void vit_linear_kernel(const b8* __restrict__ Xs, const b8* __restrict__ Wp,
                                                                     const float* __restrict__ bias, const float* __restrict__ res,
                                                                     float* __restrict__ Y, float* __restrict__ Ypre, int M, int N,
@@ -75,11 +78,24 @@ __global__ __launch_bounds__(64 * VIT_WAVES) void vit_linear_kernel(const b8* __
     for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
   const b8* wp = Wp + ((long)t * KS) * 64 + lane;
   const b8* xp = Xs + lane;
-#pragma unroll 6
-  for (int s = wv; s < KS; s += VIT_WAVES) {
-    const b8 w = wp[(long)s * 64];
+  for (int s0 = wv; s0 < KS; s0 += VIT_WAVES * NB) {
+    b8 w[NB], x[MT][NB];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = MF<b8>::mma(xp[((long)m * KS + s) * 64], w, acc[m]);
+    for (int j = 0; j < NB; ++j) {
+      const int s = s0 + j * VIT_WAVES;
+      if (s < KS) {
+        w[j] = wp[(long)s * 64];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) x[m][j] = xp[((long)m * KS + s) * 64];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      if (s0 + j * VIT_WAVES < KS) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = MF<b8>::mma(x[m][j], w[j], acc[m]);
+      }
+    }
   }
 #pragma unroll
   for (int m = 0; m < MT; ++m)
@@ -205,6 +221,17 @@ extern "C" long avc_vit_workspace_bytes(int M, int K) {
   return mt * (K / 16) * 1024L;
 }
 
+// one row tile per workgroup (M <= 128): the batch of loads a wave keeps in flight covers its whole share of K up to K = 3072
+static void vit_launch_small(dim3 grid, int lds, hipStream_t s, const b8* xs, const b8* wp, const float* bias, const float* res, float* y,
+                             float* y_pre, int M, int N, int K, int act, __bf16* ys, const float* gpre) {
+  const int per_wave = ((K >> 4) + VIT_WAVES - 1) / VIT_WAVES;
+  const dim3 block(64 * VIT_WAVES);
+  if (per_wave <= 6) hipLaunchKernelGGL((vit_linear_kernel<1, 6>), grid, block, lds, s, xs, wp, bias, res, y, y_pre, M, N, K, act, ys, gpre);
+  else if (per_wave <= 12) hipLaunchKernelGGL((vit_linear_kernel<1, 12>), grid, block, lds, s, xs, wp, bias, res, y, y_pre, M, N, K, act, ys, gpre);
+  else if (per_wave <= 18) hipLaunchKernelGGL((vit_linear_kernel<1, 18>), grid, block, lds, s, xs, wp, bias, res, y, y_pre, M, N, K, act, ys, gpre);
+  else hipLaunchKernelGGL((vit_linear_kernel<1, 24>), grid, block, lds, s, xs, wp, bias, res, y, y_pre, M, N, K, act, ys, gpre);
+}
+
 static int vit_linear_impl(const float* x, const float* x_gelu_pre, const void* w_packed, const float* bias, const float* residual,
                            float* y, float* y_pre, int M, int N, int K, int act, void* workspace, void* stream) {
   if (M <= 0) return 0;
@@ -235,7 +262,7 @@ static int vit_linear_impl(const float* x, const float* x_gelu_pre, const void* 
   } else if (batched) {
     hipLaunchKernelGGL((vit_linear_kernel<4>), grid, block, lds, s, xs, wp, bias, residual, y, y_pre, M, N, K, act);
   } else {
-    hipLaunchKernelGGL((vit_linear_kernel<1>), grid, block, lds, s, xs, wp, bias, residual, y, y_pre, M, N, K, act);
+    vit_launch_small(grid, lds, s, xs, wp, bias, residual, y, y_pre, M, N, K, act, nullptr, nullptr);
   }
   return avc_check_launch("avc_vit_linear");
 }
@@ -392,8 +419,8 @@ extern "C" int avc_vit_linear_small(const void* xs_packed, const void* w_packed,
   if (M > 32 * VIT_MAX_MT || (N & 31) || (K & 15)) { avc_set_error("avc_vit_linear_small: need M <= 128, N % 32 == 0, K % 16 == 0"); return 1; }
   if ((act == 2) != (gelu_pre != nullptr) || (!y && !ys_packed)) { avc_set_error("avc_vit_linear_small: act 2 <=> gelu_pre; y or ys_packed"); return 1; }
   const int mt = (M + 31) / 32;
-  hipLaunchKernelGGL((vit_linear_kernel<1>), dim3(N / 32, mt), dim3(64 * VIT_WAVES), VIT_WAVES * 4096, (hipStream_t)stream,
-                     (const b8*)xs_packed, (const b8*)w_packed, bias, residual, y, y_pre, M, N, K, act, (__bf16*)ys_packed, gelu_pre);
+  vit_launch_small(dim3(N / 32, mt), VIT_WAVES * 4096, (hipStream_t)stream, (const b8*)xs_packed, (const b8*)w_packed, bias, residual, y, y_pre,
+                   M, N, K, act, (__bf16*)ys_packed, gelu_pre);
   return avc_check_launch("avc_vit_linear_small");
 }
 // backward of LayerNorm over the last dimension (768) + the residual branch's gradient: dx = LN'(x; gamma)^T dy (+ res), written as

@@ -91,6 +91,11 @@ __device__ __forceinline__ void acc_to_b(const facc (&a)[2], float scale, b8 (&f
     for (int j = 0; j < 8; ++j) { f[2 * tj][j] = (bf)(a[tj][j] * scale); f[2 * tj + 1][j] = (bf)(a[tj][8 + j] * scale); }
 }
 
+// element (row, col) of a packed bf16 operand with KS k-steps per row tile = slot col & 7 of lane (row & 31, (col >> 3) & 1) of k-step
+// col >> 4 of row tile row >> 5
+__device__ __forceinline__ void put_packed_elem(bf* xs, int KS, long row, int col, float v) {
+  xs[(((row >> 5) * KS + (col >> 4)) * 64 + (row & 31) + 32 * ((col >> 3) & 1)) * 8 + (col & 7)] = (bf)v;
+}
 // PACKED: `out` is the packed bf16 operand of the out-projection ([row tile][k-step][lane (row, half)][8 columns], rows = b * 50 +
 // token) instead of fp32 [B,T,W] -- the batched scoring pipeline (avc_vit_attention_fwd_packed)
 template <bool PACKED>
@@ -127,32 +132,12 @@ __global__ __launch_bounds__(256) void vit_attn_fwd_mfma_kernel(const float* __r
 #pragma unroll
     for (int s = 0; s < 4; ++s) o = MF<b8>::mma(frag_perm(m.VT, 32 * td + n, s, h), pf[s], o);
     if (PACKED) {
-      // this lane holds, for its query, d = 32 td + 8 q + 4 h + (0..3) in registers 4 q .. 4 q + 3; a packed chunk is 8 consecutive d
-      // (k-step 4 hd + 2 td + (q >> 1), half q & 1): lane half h assembles the chunks with (q & 1) == h from its own four values and
-      // the partner half's four
-      float mine[2][4], send[2][4], got[2][4];
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          mine[e][u] = o[4 * (2 * e + h) + u];          // q = 2 e + h: stays
-          send[e][u] = o[4 * (2 * e + (1 - h)) + u];    // q = 2 e + (1 - h): the partner's chunk
-          got[e][u] = __shfl_xor(send[e][u], 32);
-        }
+      // 2-byte stores straight from the accumulator registers (a version that assembled whole 16-byte chunks through a lane-pair
+      // exchange indexed the accumulator by the lane's half -- a dynamic register index -- and took 9.1 instead of 5.3 us)
       if (i < ATM_T) {
-        const long row = (long)b * ATM_T + i;
-        const long KSo = Wd >> 4;
-        b8* xs = reinterpret_cast<b8*>(out);
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          b8 f;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            f[u] = (bf)(h == 0 ? mine[e][u] : got[e][u]);       // d = 8 q + 0..3 come from the h = 0 half
-            f[4 + u] = (bf)(h == 0 ? got[e][u] : mine[e][u]);   // d = 8 q + 4..7 from the h = 1 half
-          }
-          xs[((row >> 5) * KSo + 4 * hd + 2 * td + e) * 64 + (row & 31) + 32 * h] = f;
-        }
+        for (int r = 0; r < 16; ++r)
+          put_packed_elem(reinterpret_cast<bf*>(out), Wd >> 4, (long)b * ATM_T + i, hd * ATM_D + 32 * td + acc_row(r, h), o[r]);
       }
     } else if (i < ATM_T) {
       float* op = out + ((long)b * ATM_T + i) * Wd + hd * ATM_D + 32 * td;
@@ -162,11 +147,8 @@ __global__ __launch_bounds__(256) void vit_attn_fwd_mfma_kernel(const float* __r
   }
 }
 
-// PACKED: dqkv leaves as the packed bf16 operand of the transposed in-projection (K = 3 W; element (row, col) = slot col & 7 of lane
-// (row & 31, (col >> 3) & 1) of k-step col >> 4 of row tile row >> 5) instead of fp32 rows: the per-iteration training pipeline
-__device__ __forceinline__ void put_packed_elem(bf* xs, int KS, long row, int col, float v) {
-  xs[(((row >> 5) * KS + (col >> 4)) * 64 + (row & 31) + 32 * ((col >> 3) & 1)) * 8 + (col & 7)] = (bf)v;
-}
+// PACKED: dqkv leaves as the packed operand of the transposed in-projection (K = 3 W) instead of fp32 rows: the per-iteration training
+// pipeline (clip_vit.BlocksFn)
 template <bool PACKED>
 __global__ __launch_bounds__(256) void vit_attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                 float* __restrict__ dqkv, int Wd, int heads, float scale) {

@@ -194,7 +194,8 @@ class Engine:
     # of at most SLAB_BLOCKS 32-point blocks, rewritten slab by slab by the backward pass (backward kernel + weight-gradient kernel
     # per slab).  Every slab boundary costs the weight-gradient launch a tail (profiles/r03_slab_sweep.txt, 512^2 x 64 spp: 1 / 2 / 4
     # / 8 slabs = 39.9 / 40.5 / 41.7 / 44.2 ms), so the slab is as large as the memory allows up to SLAB_BLOCKS and is halved
-    # (down to MIN_SLAB_BLOCKS) before the ray set is cut: 512^2 x 64 spp = 87 GiB of F panels + two 46-GiB slabs; 512^2 x 128 spp
+    # (down to MIN_SLAB_BLOCKS) before the ray set is cut: 512^2 x 64 spp = 87 GiB of F panels + ONE 92-GiB slab (round 4; two 46-GiB
+    # slabs before: 121.3 -> 120.6 ms per step, profiles/r04_ab_kernels.txt); 512^2 x 128 spp
     # (BASELINE config 3 per GPU) = 174 GiB + 23-GiB slabs, still ONE chunk on a 288-GB MI355X.  Only when even that does not fit
     # the budget -- min(AVC_PANEL_GIB, 80 % of the free HBM) -- the ray set is cut into chunks and the backward re-runs the
     # training forward chunk by chunk.
@@ -207,7 +208,7 @@ class Engine:
     RING_SLOTS = int(os.environ.get("AVC_RING_SLOTS", "6"))
     RING_CHECK = os.environ.get("AVC_RING_CHECK", "0") != "0"      # synchronise after every ring launch and raise on its error word
     PANEL_BYTES_BUDGET = int(os.environ.get("AVC_PANEL_GIB", "224")) << 30
-    SLAB_BLOCKS = int(os.environ.get("AVC_SLAB_BLOCKS", str(256 * 1024)))
+    SLAB_BLOCKS = int(os.environ.get("AVC_SLAB_BLOCKS", str(512 * 1024)))
     MIN_SLAB_BLOCKS = 32 * 1024
 
     def __init__(self, spec: PK.NetSpec, device):

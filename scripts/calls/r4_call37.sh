@@ -1,0 +1,17 @@
+#!/bin/bash
+# latency linear with a wave's whole K share in flight; one slab instead of two at 512^2
+R=${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p $R/gpurun_out/r4_c37
+timeout 900 python -m pytest tests/test_gpu_clip.py -x -q -m gpu 2>&1 | tail -2
+for i in 1 2; do
+  timeout 300 python scripts/silhouette_time.py 7000 512 100 2>&1 | tail -1
+  timeout 300 python bench.py --res 224 --steps 40 --warmup 10 --no-cpu-baseline --no-extra 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('224^2 ms/step', d['ms_per_step'])"
+done 2>&1 | tee $R/gpurun_out/r4_c37/timing.txt
+for sb in 262144 524288 262144 524288; do
+  AVC_SLAB_BLOCKS=$sb timeout 300 python bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-extra 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('512^2 AVC_SLAB_BLOCKS=$sb ms/step', d['ms_per_step'], {k: round(v, 2) for k, v in d['kernel_ms_per_step'].items()})"
+done 2>&1 | tee -a $R/gpurun_out/r4_c37/timing.txt
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/kt
+rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --res 224 --steps 6 --warmup 5 --no-cpu-baseline --no-extra > /tmp/kt.log 2>&1
+python $R/scripts/rocpd_census.py /tmp/kt $R/gpurun_out/r4_c37/seq_224.txt > $R/gpurun_out/r4_c37/census_224.txt 2>&1
+grep "one step\|vit_linear\|after mlp_render" $R/gpurun_out/r4_c37/census_224.txt | cut -c1-120

@@ -122,7 +122,7 @@ def test_fullsize_one_launch_render_matches_oracle_on_256_rays():
 
 
 @gpu
-def test_fullsize_dense_gradient_of_256_rays_matches_the_oracles_autograd():
+def test_fullsize_dense_gradient_of_256_rays_matches_the_oracles_autograd(monkeypatch):
     """The backward of the 512 x 512 x 64-spp training launch against the oracle (main.py:537 through renderer.py:195-300 and
     fields.py:72-107,154-185): the loss is supported on the same 256 rays as the forward test (first / last ray, the rays at every
     4-GiB boundary of the F panel region, random ones) and has zero cotangents everywhere else, so the dense gradient that comes out
@@ -131,6 +131,8 @@ def test_fullsize_dense_gradient_of_256_rays_matches_the_oracles_autograd():
     the colour tensors, see below; 2e-2 for tensors below 1e-4 of the whole gradient's norm).  The loss takes colours, the CLIP colours, the weight sums and the normals
     (sum_i w_i n_i, main.py:428) -- not the eikonal term, whose normaliser runs over all rays of the view."""
     dev = torch.device("cuda")
+    from avatarclip_amd.engine import Engine
+    monkeypatch.setattr(Engine, "SLAB_BLOCKS", 256 * 1024)      # two slabs (the default is one slab for this ray set): the boundary is part of the test
     sdf, col, var, ren = _full_renderer(dev)
     with torch.no_grad():   # off the degenerate initialisation (the PE columns of layer 0 are zero there), as oracle/gen_golden.py does
         gp = torch.Generator().manual_seed(11)

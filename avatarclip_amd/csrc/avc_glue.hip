@@ -425,6 +425,29 @@ extern "C" int avc_chess_background(float* out, int H, int W, int chess_length, 
   return avc_check_launch("avc_chess_background");
 }
 
+// renderer.py:311-322: the coarse sample depths z[r][i] = near[r] + (far[r] - near[r]) * linspace(0, 1, n)[i] (+ (jitter[r] - 0.5) * 2 / n
+// with perturb), every float32 operation rounded like the torch op it replaces (torch.linspace: start + step * i below the middle,
+// end - step * (n - 1 - i) above).  One launch instead of nine.
+__global__ __launch_bounds__(GLUE_THREADS) void coarse_z_kernel(const float* __restrict__ near, const float* __restrict__ far,
+                                                                const float* __restrict__ jitter, int R, int n, float* __restrict__ z) {
+#pragma clang fp contract(off)   // (as in gen_rays_kernel: the torch ops this replaces are separate launches, each product and sum rounded)
+  const int t = blockIdx.x * GLUE_THREADS + threadIdx.x;
+  if (t >= R * n) return;
+  const int r = t / n, i = t % n;
+  const float lin = linspace_at(1.f, n, i);     // (torch.linspace's kernel itself contracts end - step * k into one fma: so does linspace_at)
+  const float nr = near[r];
+  float v = nr + (far[r] - nr) * lin;
+  if (jitter) v = v + (jitter[r] - 0.5f) * 2.0f / (float)n;
+  z[t] = v;
+}
+extern "C" int avc_coarse_z(const float* near, const float* far, const float* jitter, int R, int n, float* z, void* stream) {
+  if (R <= 0 || n <= 0) return 0;
+  if (!near || !far || !z) { avc_set_error("avc_coarse_z: NULL buffer"); return 1; }
+  hipLaunchKernelGGL(coarse_z_kernel, dim3(((long)R * n + GLUE_THREADS - 1) / GLUE_THREADS), dim3(GLUE_THREADS), 0, (hipStream_t)stream, near, far,
+                     jitter, R, n, z);
+  return avc_check_launch("avc_coarse_z");
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // The scalar tail of the iteration's loss (main.py:491-534) in one launch each way: the two CLIP cosines
 //   cos_b = < e_b / max(|e_b|, 1e-8), t / max(|t|, 1e-8) >,   e_b = torch.mean(enc[b:b+1], dim=0), t = torch.mean(text, dim=0)

@@ -101,3 +101,33 @@ extern "C" int avc_dense_params_bwd(int n, const void* const* v, const void* con
   hipLaunchKernelGGL(wn_bwd_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, d, dflat);
   return avc_check_launch("avc_dense_params_bwd");
 }
+
+// The packed parameter blobs of one optimisation step (engine.Packed; packing.py: pure index gathers of the flat dense vector):
+//   w16[i] = flat[idx16[i]] * scale16[i] as f16 AND as bf16 (forward / gradient sweeps), tab[i] = flat[idx32[i]] * scale32[i];
+// index nparam = the appended zero.  One launch instead of cat, 2 gathers, 2 multiplies, 2 conversions.
+__global__ __launch_bounds__(256) void pack_params_kernel(const float* __restrict__ flat, int nparam, const long* __restrict__ idx16,
+                                                          const float* __restrict__ scale16, int n16, const long* __restrict__ idx32,
+                                                          const float* __restrict__ scale32, int n32, _Float16* __restrict__ w_f16,
+                                                          __bf16* __restrict__ w_bf16, float* __restrict__ tab) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) {
+    const long k = idx16[i];
+    float w = (k < nparam ? flat[k] : 0.f) * scale16[i];
+    // the product is rounded to fp32 first, like the torch multiply it replaces: left to itself the compiler selects a mixed-precision
+    // multiply + conversion (v_fma_mixlo_f16) that rounds once and differs in the last f16 bit where the fp32 product is a tie
+    asm volatile("" : "+v"(w));
+    w_f16[i] = (_Float16)w;
+    w_bf16[i] = (__bf16)w;
+  } else if (i < n16 + n32) {
+    const int j = i - n16;
+    const long k = idx32[j];
+    tab[j] = (k < nparam ? flat[k] : 0.f) * scale32[j];
+  }
+}
+extern "C" int avc_pack_params(const float* flat, int nparam, const long* idx16, const float* scale16, int n16, const long* idx32,
+                               const float* scale32, int n32, void* w_f16, void* w_bf16, float* tab, void* stream) {
+  if (!flat || !idx16 || !scale16 || !idx32 || !scale32 || !w_f16 || !w_bf16 || !tab) { avc_set_error("avc_pack_params: NULL buffer"); return 1; }
+  hipLaunchKernelGGL(pack_params_kernel, dim3((n16 + n32 + 255) / 256), dim3(256), 0, (hipStream_t)stream, flat, nparam, idx16, scale16, n16,
+                     idx32, scale32, n32, (_Float16*)w_f16, (__bf16*)w_bf16, tab);
+  return avc_check_launch("avc_pack_params");
+}

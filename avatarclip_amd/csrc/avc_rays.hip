@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
   }
   if (nsum) { n0 = wave_sum(n0); n1 = wave_sum(n1); n2 = wave_sum(n2); }
   if (lane == 0 && active) {
-    if (wstat) { wstat[2 * ray] = ws; wstat[2 * ray + 1] = wm; }
+    if (wstat) { wstat[ray] = ws; wstat[(long)R + ray] = wm; }    // planar [2][R]: both rows are the [R,1] tensors render() returns
     if (nsum) { nsum[3 * ray] = n0; nsum[3 * ray + 1] = n1; nsum[3 * ray + 2] = n2; }
     float b0 = 0, b1 = 0, b2 = 0;
     if (bg_mode == 1) { b0 = bg[0]; b1 = bg[1]; b2 = bg[2]; }
@@ -395,4 +395,50 @@ extern "C" int avc_composite_bwd(const float* sdf, const float* normal, const fl
                      z, rays_o, rays_d, R, S, inv_s, sample_dist, cos_anneal, bg, bg_mode, d_color, d_extra, d_weights,
                      d_normal_up, d_wsum, d_nsum, eik_scale, d_sdf, d_normal, d_rgb, d_inv_s);
   return avc_check_launch("avc_composite_bwd");
+}
+
+// Column sums of x [R,C] (C <= 4) by ONE workgroup in a fixed order (thread t adds rows t, t + 1024, ..; lanes; waves) -- the scalar
+// reductions around the compositing kernels without a torch reduction + its bookkeeping launches each:
+//   mode 0: out[c] = sum_r x[r][c]
+//   mode 1 (renderer.py:283-285, the eikonal term from avc_composite_fwd's eik [R,2]): out[1] = sum x[:,1] + 1e-5, out[0] = sum x[:,0] / out[1]
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ x, long R, int C, int mode, float* __restrict__ out) {
+  __shared__ float red[4][16];
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (long r = threadIdx.x; r < R; r += 1024)
+    for (int c = 0; c < C; ++c) acc[c] += x[r * C + c];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int c = 0; c < C; ++c) {
+    float v = acc[c];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if (lane == 0) red[c][wv] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C; ++c)
+      for (int w = 0; w < 16; ++w) s[c] += red[c][w];
+    if (mode == 1) { const float den = s[1] + 1e-5f; out[1] = den; out[0] = s[0] / den; }
+    else for (int c = 0; c < C; ++c) out[c] = s[c];
+  }
+}
+extern "C" int avc_colsum(const float* x, long R, int C, int mode, float* out, void* stream) {
+  if (C < 1 || C > 4 || (mode == 1 && C != 2) || R < 0 || (!x && R > 0) || !out) {    // (R == 0: the sums of nothing, x may be NULL)
+    avc_set_error("avc_colsum: 1 <= C <= 4 (mode 1: C == 2), buffers");
+    return 1;
+  }
+  hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, R, C, mode, out);
+  return avc_check_launch("avc_colsum");
+}
+// inv_s = exp(10 variance).clip(1e-6, 1e6) (fields.py:275-276 + renderer.py:234) and its backward: g == NULL: out[0] = inv_s;
+// else out[0] = g[0] * d inv_s / d variance (10 exp(10 v) inside the clip range, ends included, else 0)
+__global__ void inv_s_kernel(const float* __restrict__ variance, const float* __restrict__ g, float* __restrict__ out) {
+  const float e = expf(variance[0] * 10.0f);
+  if (!g) out[0] = fminf(fmaxf(e, 1e-6f), 1e6f);
+  else out[0] = (e >= 1e-6f && e <= 1e6f) ? g[0] * (e * 10.0f) : 0.f;
+}
+extern "C" int avc_inv_s(const float* variance, const float* g, float* out, void* stream) {
+  if (!variance || !out) { avc_set_error("avc_inv_s: NULL buffer"); return 1; }
+  hipLaunchKernelGGL(inv_s_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, variance, g, out);
+  return avc_check_launch("avc_inv_s");
 }

@@ -50,16 +50,28 @@ class _DevLayout:
         return cls._cache[key]
 
 
+FUSED_PACK = os.environ.get("AVC_FUSED_PACK", "1") != "0"      # Packed / the coarse sample depths as one launch each (0: torch ops)
+
+
 class Packed:
     """Packed parameter blobs of one optimisation step."""
 
     def __init__(self, dl: _DevLayout, flatP: torch.Tensor):
+        self.dl = dl
+        if flatP.is_cuda and FUSED_PACK:     # one launch (csrc/avc_params.hip); below: the torch statement of the same gathers
+            f = flatP.detach().float().contiguous()
+            n16, n32 = dl.idx16.numel(), dl.idx32.numel()
+            self.w_f16 = torch.empty(n16, dtype=torch.float16, device=f.device)
+            self.w_bf16 = torch.empty(n16, dtype=torch.bfloat16, device=f.device)
+            self.tab = torch.empty(n32, dtype=torch.float32, device=f.device)
+            L.check(L.load().avc_pack_params(L.ptr(f), f.numel(), L.ptr(dl.idx16), L.ptr(dl.scale16), n16, L.ptr(dl.idx32), L.ptr(dl.scale32), n32,
+                                             L.ptr(self.w_f16), L.ptr(self.w_bf16), L.ptr(self.tab), L.stream()), "avc_pack_params")
+            return
         pz = torch.cat([flatP.detach().float(), flatP.new_zeros(1)])
         w = pz[dl.idx16] * dl.scale16
         self.w_f16 = w.to(torch.float16).contiguous()
         self.w_bf16 = w.to(torch.bfloat16).contiguous()
         self.tab = (pz[dl.idx32] * dl.scale32).contiguous()
-        self.dl = dl
 
 
 def flatten_dense_torch(sdf_net, col_net, spec: PK.NetSpec) -> torch.Tensor:
@@ -421,7 +433,7 @@ class Engine:
         return out
 
     def composite_fwd(self, sdf, nrm, rgb, z, rays_o, rays_d, inv_s, sample_dist, cos_anneal, bg, bg_mode):
-        """-> color, extra, weights, cdf, mid_z, inside, eik, wstat [R,2] = (sum_i w_i, max_i w_i), nsum [R,3] = sum_i w_i n_i"""
+        """-> color, extra, weights, cdf, mid_z, inside, eik, wstat [2,R] = (sum_i w_i, max_i w_i), nsum [R,3] = sum_i w_i n_i"""
         R, S = z.shape
         dev, f32 = self.device, torch.float32
         color = torch.empty(R, 3, device=dev, dtype=f32)
@@ -431,7 +443,7 @@ class Engine:
         mid_z = torch.empty(R, S, device=dev, dtype=f32)
         inside = torch.empty(R, S, device=dev, dtype=f32)
         eik = torch.empty(R, 2, device=dev, dtype=f32)
-        wstat = torch.empty(R, 2, device=dev, dtype=f32)
+        wstat = torch.empty(2, R, device=dev, dtype=f32)
         nsum = torch.empty(R, 3, device=dev, dtype=f32)
         L.check(self.lib.avc_composite_fwd(L.ptr(sdf), L.ptr(nrm), L.ptr(rgb), L.ptr(z), L.ptr(rays_o), L.ptr(rays_d), R, S,
                                            L.ptr(inv_s), float(sample_dist), float(cos_anneal), L.ptr(bg), bg_mode,
@@ -583,14 +595,18 @@ class RenderCoreFn(torch.autograd.Function):
             sdf, nrm, rgb = eng.points_fwd(pk, rays_o, rays_d, z_vals, sample_dist)
         color, extra, weights, cdf, mid_z, inside, eik, wstat, nsum = eng.composite_fwd(
             sdf, nrm, rgb, z_vals, rays_o, rays_d, inv_s_d, sample_dist, cos_anneal, bg, bg_mode)
-        wsum, wmax = wstat[:, 0:1].contiguous(), wstat[:, 1:2].contiguous()
-        eik_den = eik[:, 1].sum() + 1e-5
-        gerr = eik[:, 0].sum() / eik_den
+        wsum, wmax = wstat[0].reshape(R, 1), wstat[1].reshape(R, 1)       # (planar: views, no copies)
+        eo = torch.empty(2, device=eik.device, dtype=torch.float32)        # renderer.py:283-285 in one launch: (gradient_error, its denominator)
+        L.check(eng.lib.avc_colsum(L.ptr(eik), R, 2, 1, L.ptr(eo), L.stream()), "avc_colsum")
+        gerr, eik_den = eo[0], eo[1]
         ctx.eng, ctx.pk = eng, pk
         ctx.consts = (sample_dist, cos_anneal, bg_mode)
         ctx.save_for_backward(rays_o, rays_d, z_vals, sdf, nrm, rgb, inv_s_d, eik_den, bg if bg is not None else inv_s_d)
         ctx.has_bg = bg is not None
         ctx.mark_non_differentiable(cdf, mid_z, inside, sdf, wmax)
+        # outputs the loss does not touch (the per-sample weights and normals when the shading takes wsum / nsum) hand `None` to the
+        # backward instead of zero tensors: [R,S] + [R,S,3] fp32 of fills and of reads in composite_bwd per step otherwise
+        ctx.set_materialize_grads(False)
         # wsum = sum_i w_i, wmax = max_i w_i, nsum = sum_i w_i n_i: the per-ray reductions render() and the shading of main.py:428
         # take of the weights, out of the compositing kernel's own registers (and differentiable through its reverse scan)
         return color, extra, weights, nrm, gerr, cdf, mid_z, inside, sdf, wsum, wmax, nsum
@@ -618,4 +634,6 @@ class RenderCoreFn(torch.autograd.Function):
                                                      d_wsum, d_nsum)
         valid = ctx.panel_token is not None and eng._panel_owner is ctx.panel_token
         grad = eng.points_bwd(pk, rays_o, rays_d, z_vals, sample_dist, d_sdf, d_n, d_rgb, rgb, panels_valid=valid)
-        return grad, d_inv.sum().reshape(1), None, None, None, None, None, None, None, None
+        d_inv_s = torch.empty(1, device=d_inv.device, dtype=torch.float32)
+        L.check(eng.lib.avc_colsum(L.ptr(d_inv), R, 1, 0, L.ptr(d_inv_s), L.stream()), "avc_colsum")
+        return grad, d_inv_s, None, None, None, None, None, None, None, None

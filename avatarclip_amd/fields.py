@@ -178,5 +178,29 @@ class SingleVarianceNetwork(nn.Module):
         return torch.ones([len(x), 1], device=self.variance.device) * torch.exp(self.variance * 10.0)
 
     def inv_s(self):
-        """exp(10 v).clip(1e-6, 1e6) as a 1-element tensor (fields.py:275-276 + renderer.py:234)."""
+        """exp(10 v).clip(1e-6, 1e6) as a 1-element tensor (fields.py:275-276 + renderer.py:234); on the GPU one launch each way
+        (csrc/avc_rays.hip inv_s_kernel) instead of three forward and seven backward."""
+        if self.variance.is_cuda:
+            return _InvSFn.apply(self.variance)
         return torch.exp(self.variance * 10.0).clip(1e-6, 1e6).reshape(1)
+
+
+class _InvSFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, variance):
+        from . import lib as L
+        v = variance.detach().float().reshape(1).contiguous()
+        out = torch.empty(1, device=v.device, dtype=torch.float32)
+        L.check(L.load().avc_inv_s(L.ptr(v), None, L.ptr(out), L.stream()), "avc_inv_s")
+        ctx.save_for_backward(v)
+        ctx.shape = variance.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import lib as L
+        (v,) = ctx.saved_tensors
+        g = g.float().reshape(1).contiguous()
+        out = torch.empty(1, device=v.device, dtype=torch.float32)
+        L.check(L.load().avc_inv_s(L.ptr(v), L.ptr(g), L.ptr(out), L.stream()), "avc_inv_s")
+        return out.reshape(ctx.shape)

@@ -30,6 +30,7 @@ class _Ring:
     def __init__(self, device):
         self.device = device
         self.buf = torch.empty(self.SLOTS, self.WIDTH, dtype=torch.float64).pin_memory()
+        self.buf32 = torch.empty(self.SLOTS, self.WIDTH, dtype=torch.float32).pin_memory()   # float32 values travel as float32: no conversion launch
         self.events = [None] * self.SLOTS
         self.i = 0
 
@@ -41,8 +42,12 @@ class _Ring:
         ev = self.events[slot]
         if ev is not None:
             ev.synchronize()
-        row = self.buf[slot, :n]
-        row.copy_(torch.from_numpy(a.reshape(-1)))
+        if dtype == torch.float32:
+            row = self.buf32[slot, :n]
+            row.copy_(torch.from_numpy(a.reshape(-1).astype(np.float32)))
+        else:
+            row = self.buf[slot, :n]
+            row.copy_(torch.from_numpy(a.reshape(-1)))
         with torch.cuda.device(self.device):     # the copy AND its guard event go to this device's current stream
             out = row.to(self.device, non_blocking=True).to(dtype).reshape(a.shape)
             ev = torch.cuda.Event()

@@ -52,6 +52,10 @@ _SIGS = {
     "avc_weight_grad_unpack": (c_int, [P, P, P, P, c_int, P, P]),
     "avc_shade_loss_blocks": (c_int, [c_int]),
     "avc_shade_loss_fwd": (c_int, [P, P, P, P, P, P, P, P, c_float, P, c_int, c_int, P, P, P, P, P]),
+    "avc_colsum": (c_int, [P, c_long, c_int, c_int, P, P]),
+    "avc_inv_s": (c_int, [P, P, P, P]),
+    "avc_pack_params": (c_int, [P, c_int, P, P, c_int, P, P, c_int, P, P, P, P]),
+    "avc_coarse_z": (c_int, [P, P, P, c_int, c_int, P, P]),
     "avc_loss_tail_fwd": (c_int, [P, P, c_int, c_int, c_int, P, P, c_float, c_float, c_float, c_float, P, P, P, P]),
     "avc_loss_tail_bwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P, c_float, c_float, c_float, c_float, P, P, P]),
     "avc_shade_loss_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P, P, P, P, P]),

@@ -53,13 +53,21 @@ class NeuSRenderer:
         eng = self.engine
         R = rays_o.shape[0]
         dev = rays_o.device
-        z = torch.linspace(0.0, 1.0, self.n_samples, device=dev)
-        z = near + (far - near) * z[None, :]
-        if perturb > 0:
-            if jitter is None:
-                jitter = torch.rand([R, 1], device=dev)
-            z = z + (jitter - 0.5) * 2.0 / self.n_samples
-        z = z.contiguous()
+        if perturb > 0 and jitter is None:
+            jitter = torch.rand([R, 1], device=dev)
+        from .engine import FUSED_PACK
+        if dev.type == "cuda" and FUSED_PACK and near.numel() == R and far.numel() == R:
+            from . import lib as L
+            near_c, far_c = near.reshape(R).contiguous().float(), far.reshape(R).contiguous().float()
+            jit = jitter.reshape(R).contiguous().float() if perturb > 0 else None
+            z = torch.empty(R, self.n_samples, device=dev, dtype=torch.float32)
+            L.check(L.load().avc_coarse_z(L.ptr(near_c), L.ptr(far_c), L.ptr(jit), R, self.n_samples, L.ptr(z), L.stream()), "avc_coarse_z")
+        else:
+            z = torch.linspace(0.0, 1.0, self.n_samples, device=dev)
+            z = near + (far - near) * z[None, :]
+            if perturb > 0:
+                z = z + (jitter - 0.5) * 2.0 / self.n_samples
+            z = z.contiguous()
         steps = []
         if self.n_importance > 0:
             sdf = eng.sdf_rays(pk, rays_o, rays_d, z)

@@ -57,12 +57,18 @@ long avc_fwd_scratch_bytes_per_wave(int net);
  * bg_mode 0: none, 1: bg[3] shared, 2: bg[R] grey per ray (main.py:387-415); background is composited into
  * `extra` only (renderer.py:277-281).  Outputs: color[R,3], extra[R,3], weights[R,S], cdf[R,S], mid_z[R,S],
  * inside[R,S], eik[R,2] = per-ray (sum relax*(|n|-1)^2, sum relax); optional (NULL = skip) per-ray reductions of the weights
- * that the callers of render() take next: wstat[R,2] = (sum_i w_i, max_i w_i) (renderer.py:391-392 weight_sum / weight_max)
+ * that the callers of render() take next: wstat[2][R] = (sum_i w_i, max_i w_i) (renderer.py:391-392 weight_sum / weight_max)
  * and nsum[R,3] = sum_i w_i n_i (the shading normal of main.py:428 before its normalisation). */
 int avc_composite_fwd(const float* sdf, const float* normal, const float* rgb, const float* z, const float* rays_o,
                       const float* rays_d, int R, int S, const float* inv_s /* device scalar */, float sample_dist,
                       float cos_anneal, const float* bg, int bg_mode, float* color, float* extra, float* weights,
                       float* cdf, float* mid_z, float* inside, float* eik, float* wstat, float* nsum, void* stream);
+
+/* The scalar reductions around the compositing kernels in one launch each: column sums of x [R,C] (C <= 4) in a fixed order; mode 1
+ * (x = avc_composite_fwd's eik): out[1] = sum x[:,1] + 1e-5, out[0] = sum x[:,0] / out[1] = the eikonal term of renderer.py:283-285.
+ * avc_inv_s: out[0] = exp(10 variance).clip(1e-6, 1e6) (fields.py:275-276, renderer.py:234); with g != NULL its backward g[0] * d/dv. */
+int avc_colsum(const float* x, long R, int C, int mode, float* out, void* stream);
+int avc_inv_s(const float* variance, const float* g, float* out, void* stream);
 
 /* Reverse of avc_composite_fwd.  Upstream: d_color[R,3], d_extra[R,3], d_weights[R,S] (may be NULL), d_normal_up[R,S,3] (may
  * be NULL), d_wsum[R] / d_nsum[R,3] = gradients of wstat[:,0] / nsum (may be NULL), eik_scale = d(loss)/d(eik) / (sum relax +
@@ -168,6 +174,13 @@ int avc_shade_loss_fwd(const float* color, const float* extra, const float* wsum
 int avc_shade_loss_bwd(const float* color, const float* extra, const float* wsum, const float* nsum, const float* true_rgb,
                        const float* mask, const int* ray_of_pixel, const float* light, int P, int img0_is_extra, const float* dimg0,
                        const float* dimg1, const float* gs, float* dcolor, float* dextra, float* dwsum, float* dnsum, void* stream);
+/* engine.Packed in one launch: w_f16 / w_bf16 [n16] = flat[idx16] * scale16 (both 16-bit types), tab [n32] = flat[idx32] * scale32; an
+ * index >= nparam reads the appended zero (packing.py: the blobs are pure index gathers of the dense vector, fields.py:65-66,139-143). */
+int avc_pack_params(const float* flat, int nparam, const long* idx16, const float* scale16, int n16, const long* idx32,
+                    const float* scale32, int n32, void* w_f16, void* w_bf16, float* tab, void* stream);
+/* renderer.py:311-322: z [R,n] = near + (far - near) * linspace(0, 1, n) (+ (jitter - 0.5) * 2 / n; jitter [R] or NULL), rounded like
+ * the torch ops */
+int avc_coarse_z(const float* near_, const float* far_, const float* jitter, int R, int n, float* z, void* stream);
 /* The scalar tail of the loss (main.py:491-534) in one launch each way: cos_b = torch.cosine_similarity(torch.mean(enc[b:b+1], 0),
  * torch.mean(text, 0), dim=0) for the B images (enc [B,512], text [T,512]) and
  *   loss = sums[0] / (sums[1] + 1e-5) + eikonal * igr_weight + (sums[2] / P) * mask_weight + sum_b (1 - cos_b) * clip_weight

@@ -170,7 +170,7 @@ def test_composite_forward_backward_fp32():
         torch.cuda.synchronize()
         color, extra, w, cdf, mid_z, inside, eik, wstat, nsum = [o.cpu() for o in out]
         # the per-ray reductions of the weights the kernel hands out beside them (renderer.py:391-392, main.py:428)
-        assert torch.allclose(wstat[:, 0], w.sum(-1), atol=1e-5) and torch.allclose(wstat[:, 1], w.max(-1)[0], atol=1e-7)
+        assert torch.allclose(wstat[0], w.sum(-1), atol=1e-5) and torch.allclose(wstat[1], w.max(-1)[0], atol=1e-7)
         assert torch.allclose(nsum, (n * w[..., None]).sum(1), atol=1e-5)
         assert torch.allclose(color.double(), cf["color"], atol=2e-5)
         assert torch.allclose(extra.double(), cf["extra"], atol=2e-5)
@@ -317,3 +317,51 @@ def test_fused_dense_parameter_assembly_matches_torch_weight_norm(extra_color, w
     # the SDF-only path (no colour net): zeros behind the SDF block
     c = flatten_dense(sdf, None, PK.FULL)
     assert torch.equal(c[: a.numel()][c != 0], a[c != 0]) and c.numel() == a.numel()
+
+
+@gpu
+def test_head_fusions_equal_their_torch_statements(monkeypatch):
+    """The single-launch forms of the iteration's small steps against the torch ops they replace: the packed parameter blobs (bit for
+    bit), the coarse sample depths (bit for bit, with and without jitter), inv_s and its backward, the column sums around the
+    compositing kernels."""
+    import avatarclip_amd.engine as E
+    from avatarclip_amd import fields, lib as L, packing as PK
+    dev = torch.device("cuda")
+    lib = L.load()
+    for spec in (PK.NetSpec(128, 2, 1), PK.NetSpec(256, 2, 1)):
+        dl = E._DevLayout.get(spec, dev)
+        flat = torch.randn(dl.lay.nparam, generator=torch.Generator().manual_seed(1)).to(dev) * 0.3
+        monkeypatch.setattr(E, "FUSED_PACK", True)
+        a = E.Packed(dl, flat)
+        monkeypatch.setattr(E, "FUSED_PACK", False)
+        b = E.Packed(dl, flat)
+        assert torch.equal(a.w_f16, b.w_f16) and torch.equal(a.w_bf16, b.w_bf16) and torch.equal(a.tab, b.tab)
+    from tests.test_gpu_ring import _nets
+    ren = _nets(True, dev)
+    g = torch.Generator().manual_seed(2)
+    R = 777
+    near, far = (torch.rand(R, 1, generator=g) * 0.8 + 0.3).to(dev), (torch.rand(R, 1, generator=g) + 2.0).to(dev)
+    jit = torch.rand(R, 1, generator=g).to(dev)
+    ro = torch.zeros(R, 3, device=dev); rd = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1).to(dev)
+    ren.n_importance = 0            # sample_z then returns the coarse depths
+    for perturb, j in ((0, None), (1.0, jit)):
+        zs = []
+        for fused in (True, False):
+            monkeypatch.setattr(E, "FUSED_PACK", fused)
+            zs.append(ren.sample_z(None, ro, rd, near, far, perturb, j))
+        assert zs[0].shape == (R, ren.n_samples) and torch.equal(zs[0], zs[1]), (perturb, (zs[0] - zs[1]).abs().max())
+    for v0 in (0.3, 0.05, -1.5, 1.45):       # (-1.5 and 1.45: outside the clip range -> zero gradient)
+        net = fields.SingleVarianceNetwork(v0).to(dev)
+        y = net.inv_s()
+        (y * 1.7).sum().backward()
+        vr = torch.tensor(v0, device=dev, requires_grad=True)
+        yr = torch.exp(vr * 10.0).clip(1e-6, 1e6).reshape(1)
+        (yr * 1.7).sum().backward()
+        assert torch.allclose(y.detach(), yr.detach(), rtol=2e-6) and torch.allclose(net.variance.grad, vr.grad, rtol=2e-6), (v0, y, yr)
+    x = torch.rand(100003, 2, generator=g).to(dev)
+    out = torch.empty(2, device=dev)
+    L.check(lib.avc_colsum(L.ptr(x), x.shape[0], 2, 1, L.ptr(out), L.stream()), "colsum")
+    den = x[:, 1].double().sum() + 1e-5
+    assert abs(out[1].item() - den.item()) < 1e-5 * den.item() and abs(out[0].item() - (x[:, 0].double().sum() / den).item()) < 1e-5
+    L.check(lib.avc_colsum(L.ptr(x), x.shape[0], 2, 0, L.ptr(out), L.stream()), "colsum")
+    assert torch.allclose(out.double(), x.double().sum(0), rtol=1e-5)

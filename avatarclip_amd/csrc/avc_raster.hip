@@ -66,15 +66,43 @@ __device__ __forceinline__ bool face_box(const FaceEq& e, int is, int& xa, int& 
   return xb >= xa && yb >= ya;
 }
 
+// the nine floats of face fn: from faces [F,9], or (idx != NULL) gathered from the projected vertices faces = ndc [V,3] through idx [F,3]
+__device__ __forceinline__ void load_face(const float* __restrict__ faces, const int* __restrict__ idx, int fn, float (&f)[9]) {
+  if (idx) {
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      const long vi = idx[3 * (long)fn + v];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) f[3 * v + k] = faces[3 * vi + k];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) f[k] = faces[(long)fn * 9 + k];
+  }
+}
+// neural_renderer's look + perspective (look.py, perspective.py; models/utils.py:108-125): v_cam = (v - eye) . (x, y, z axes),
+// ndc = (x / z / width, y / z / width, z); cam = device [12]: eye, x axis, y axis, z axis
+__global__ __launch_bounds__(256) void prior_project_kernel(const float* __restrict__ vw, int V, const float* __restrict__ cam, float width,
+                                                            float* __restrict__ ndc) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= V) return;
+  const float d0 = vw[3 * i] - cam[0], d1 = vw[3 * i + 1] - cam[1], d2 = vw[3 * i + 2] - cam[2];
+  float c[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) c[j] = fmaf(d2, cam[3 + 3 * j + 2], fmaf(d1, cam[3 + 3 * j + 1], d0 * cam[3 + 3 * j]));
+  ndc[3 * i] = c[0] / c[2] / width;
+  ndc[3 * i + 1] = c[1] / c[2] / width;
+  ndc[3 * i + 2] = c[2];
+}
 // `large` = [count - 1 (0xFFFFFFFF = none), face indices ...]
-__global__ __launch_bounds__(256) void raster_faces_kernel(const float* __restrict__ faces /* [F,9] x,y (NDC), z (depth) */, int F, int is,
+__global__ __launch_bounds__(256) void raster_faces_kernel(const float* __restrict__ faces /* [F,9] x,y (NDC), z (depth) */,
+                                                           const int* __restrict__ idx, int F, int is,
                                                            float near, float far, unsigned long long* __restrict__ zbuf /* [is,is], y up */,
                                                            unsigned* __restrict__ large) {
   const int fn = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (fn >= F) return;
   float f[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) f[k] = faces[(long)fn * 9 + k];
+  load_face(faces, idx, fn, f);
   FaceEq e;
   if (!face_setup(f, is, e)) return;
   int xa, xb, ya, yb;
@@ -94,8 +122,8 @@ __global__ __launch_bounds__(256) void raster_faces_kernel(const float* __restri
 }
 // the listed large faces, tile-parallel: thread = pixel of a 16 x 16 tile, every face of the list whose box meets the tile is
 // evaluated at the tile's pixels; the running minimum joins the key the small faces left (plain read-modify-write: one thread per pixel)
-__global__ __launch_bounds__(256) void raster_large_kernel(const float* __restrict__ faces, int is, float near, float far,
-                                                           unsigned long long* __restrict__ zbuf, const unsigned* __restrict__ large) {
+__global__ __launch_bounds__(256) void raster_large_kernel(const float* __restrict__ faces, const int* __restrict__ idx, int is, float near,
+                                                           float far, unsigned long long* __restrict__ zbuf, const unsigned* __restrict__ large) {
   const unsigned nl = large[0] + 1u;
   if (nl == 0u) return;
   const int tx0 = blockIdx.x * RS_TILE, ty0 = blockIdx.y * RS_TILE;
@@ -104,8 +132,7 @@ __global__ __launch_bounds__(256) void raster_large_kernel(const float* __restri
   for (unsigned q = 0; q < nl; ++q) {
     const int fn = (int)large[1 + q];
     float f[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) f[k] = faces[(long)fn * 9 + k];
+    load_face(faces, idx, fn, f);
     FaceEq e;
     if (!face_setup(f, is, e)) continue;
     int xa, xb, ya, yb;
@@ -134,6 +161,32 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(unsigned long long*
   zbuf[p] = RS_EMPTY;
 }
 
+// the same + what models/utils.py:108-125 does next, for the 2 x super-sampled render (anti_aliasing): 2 x 2 average (avg_pool2d: the window
+// summed row by row, then / 4), optionally the x flip of models/utils.py:124 (`[:, ::-1]`) and the white texture's three equal channels.
+// out [S,S] (channels == 1) or [S,S,3], S = is / 2.
+__global__ __launch_bounds__(256) void raster_resolve_pool_kernel(unsigned long long* __restrict__ zbuf, const float* __restrict__ light, int is,
+                                                                  float* __restrict__ out, int flip_x, int channels, unsigned* __restrict__ large) {
+  const int S = is >> 1;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p == 0) large[0] = 0xFFFFFFFFu;
+  if (p >= S * S) return;
+  const int y = p / S, x = p % S;
+  float acc = 0.f;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int r = 2 * y + dy, c = 2 * x + dx;                       // image row r (0 = top) is z-buffer row is - 1 - r
+      unsigned long long* z = &zbuf[(long)(is - 1 - r) * is + c];
+      const unsigned long long key = *z;
+      acc += key == RS_EMPTY ? 0.f : light[(unsigned)(key & 0xFFFFFFFFull)];
+      *z = RS_EMPTY;
+    }
+  const float v = acc / 4.f;
+  const int xo = flip_x ? S - 1 - x : x;
+  for (int ch = 0; ch < channels; ++ch) out[((long)y * S + xo) * channels + ch] = v;
+}
+
 extern "C" long avc_rasterize_scratch_bytes(int F, int image_size) {
   return (long)image_size * image_size * 8 + ((long)F + 2) * 4;
 }
@@ -146,10 +199,30 @@ extern "C" int avc_rasterize_faces(const float* faces, const float* light, int F
   unsigned long long* zbuf = (unsigned long long*)scratch;
   unsigned* large = (unsigned*)(zbuf + (long)image_size * image_size);
   if (F) {
-    hipLaunchKernelGGL(raster_faces_kernel, dim3((F + 3) / 4), dim3(256), 0, s, faces, F, image_size, near, far, zbuf, large);
+    hipLaunchKernelGGL(raster_faces_kernel, dim3((F + 3) / 4), dim3(256), 0, s, faces, (const int*)nullptr, F, image_size, near, far, zbuf, large);
     const int nt = (image_size + RS_TILE - 1) / RS_TILE;
-    hipLaunchKernelGGL(raster_large_kernel, dim3(nt, nt), dim3(256), 0, s, faces, image_size, near, far, zbuf, large);
+    hipLaunchKernelGGL(raster_large_kernel, dim3(nt, nt), dim3(256), 0, s, faces, (const int*)nullptr, image_size, near, far, zbuf, large);
   }
   hipLaunchKernelGGL(raster_resolve_kernel, dim3((image_size * image_size + 255) / 256), dim3(256), 0, s, zbuf, light, image_size, image, large);
   return avc_check_launch("avc_rasterize_faces");
+}
+// The whole prior render of models/utils.py:108-125 from the world-space mesh: projection of the V vertices (cam = device [12]: eye + the
+// look frame's x, y, z axes; width = tan(viewing angle)), the rasteriser above on faces gathered through idx [F,3] (fill_back copies
+// included) at the 2 x super-sampled size 2 S, and the 2 x 2 average (+ x flip, + 3 equal channels) -> out [S,S(,3)].  ndc: [V,3] scratch.
+extern "C" int avc_rasterize_mesh(const float* v_world, int V, const int* idx, int F, const float* cam, float width, const float* light,
+                                  int S, float near, float far, float* ndc, float* out, int flip_x, int channels, void* scratch, void* stream) {
+  if (S <= 0 || V <= 0 || F < 0 || near < 0.f || (channels != 1 && channels != 3)) { avc_set_error("avc_rasterize_mesh: bad sizes"); return 1; }
+  if (!v_world || !cam || !ndc || !out || !scratch || (F && (!idx || !light))) { avc_set_error("avc_rasterize_mesh: NULL buffer"); return 1; }
+  hipStream_t s = (hipStream_t)stream;
+  const int is = 2 * S;
+  unsigned long long* zbuf = (unsigned long long*)scratch;
+  unsigned* large = (unsigned*)(zbuf + (long)is * is);
+  hipLaunchKernelGGL(prior_project_kernel, dim3((V + 255) / 256), dim3(256), 0, s, v_world, V, cam, width, ndc);
+  if (F) {
+    hipLaunchKernelGGL(raster_faces_kernel, dim3((F + 3) / 4), dim3(256), 0, s, ndc, idx, F, is, near, far, zbuf, large);
+    const int nt = (is + RS_TILE - 1) / RS_TILE;
+    hipLaunchKernelGGL(raster_large_kernel, dim3(nt, nt), dim3(256), 0, s, ndc, idx, is, near, far, zbuf, large);
+  }
+  hipLaunchKernelGGL(raster_resolve_pool_kernel, dim3((S * S + 255) / 256), dim3(256), 0, s, zbuf, light, is, out, flip_x, channels, large);
+  return avc_check_launch("avc_rasterize_mesh");
 }

@@ -397,14 +397,20 @@ extern "C" int avc_composite_bwd(const float* sdf, const float* normal, const fl
   return avc_check_launch("avc_composite_bwd");
 }
 
-// Column sums of x [R,C] (C <= 4) by ONE workgroup in a fixed order (thread t adds rows t, t + 1024, ..; lanes; waves) -- the scalar
+// Column sums of x [R,C] (C <= 4) in a fixed order -- up to CS_BLOCKS workgroups each add a contiguous range of rows (thread t: rows
+// t, t + 1024, ..; lanes; waves), the one that finishes last (ticket) adds the per-workgroup sums in workgroup order -- the scalar
 // reductions around the compositing kernels without a torch reduction + its bookkeeping launches each:
 //   mode 0: out[c] = sum_r x[r][c]
 //   mode 1 (renderer.py:283-285, the eikonal term from avc_composite_fwd's eik [R,2]): out[1] = sum x[:,1] + 1e-5, out[0] = sum x[:,0] / out[1]
-__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ x, long R, int C, int mode, float* __restrict__ out) {
+// scratch: CS_BLOCKS x 4 floats + one zero-initialised word that the kernel leaves zero.
+#define CS_BLOCKS 64
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ x, long R, int C, int mode, float* __restrict__ out,
+                                                      float* __restrict__ part, unsigned* __restrict__ ticket) {
   __shared__ float red[4][16];
+  __shared__ bool last;
+  const long per = (R + gridDim.x - 1) / gridDim.x, r0 = per * blockIdx.x, r1 = min(R, r0 + per);
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (long r = threadIdx.x; r < R; r += 1024)
+  for (long r = r0 + threadIdx.x; r < r1; r += 1024)
     for (int c = 0; c < C; ++c) acc[c] += x[r * C + c];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (int c = 0; c < C; ++c) {
@@ -415,26 +421,40 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < C; ++c)
-      for (int w = 0; w < 16; ++w) s[c] += red[c][w];
-    if (mode == 1) { const float den = s[1] + 1e-5f; out[1] = den; out[0] = s[0] / den; }
-    else for (int c = 0; c < C; ++c) out[c] = s[c];
+    for (int c = 0; c < C; ++c) {
+      float v = 0.f;
+      for (int w = 0; w < 16; ++w) v += red[c][w];
+      part[4 * blockIdx.x + c] = v;
+    }
+    __threadfence();
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
   }
+  __syncthreads();
+  if (!last || threadIdx.x != 0) return;
+  __threadfence();
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < (int)gridDim.x; ++b)
+    for (int c = 0; c < C; ++c) s[c] += part[4 * b + c];
+  if (mode == 1) { const float den = s[1] + 1e-5f; out[1] = den; out[0] = s[0] / den; }
+  else for (int c = 0; c < C; ++c) out[c] = s[c];
+  *ticket = 0u;
 }
-extern "C" int avc_colsum(const float* x, long R, int C, int mode, float* out, void* stream) {
-  if (C < 1 || C > 4 || (mode == 1 && C != 2) || R < 0 || (!x && R > 0) || !out) {    // (R == 0: the sums of nothing, x may be NULL)
+extern "C" long avc_colsum_scratch_bytes() { return (CS_BLOCKS * 4 + 1) * 4; }
+extern "C" int avc_colsum(const float* x, long R, int C, int mode, float* out, void* scratch, void* stream) {
+  if (C < 1 || C > 4 || (mode == 1 && C != 2) || R < 0 || (!x && R > 0) || !out || !scratch) {    // (R == 0: the sums of nothing, x may be NULL)
     avc_set_error("avc_colsum: 1 <= C <= 4 (mode 1: C == 2), buffers");
     return 1;
   }
-  hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, R, C, mode, out);
+  const int nb = (int)max(1L, min((long)CS_BLOCKS, (R + 4095) / 4096));
+  float* part = (float*)scratch;
+  hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(1024), 0, (hipStream_t)stream, x, R, C, mode, out, part, (unsigned*)(part + CS_BLOCKS * 4));
   return avc_check_launch("avc_colsum");
 }
-// inv_s = exp(10 variance).clip(1e-6, 1e6) (fields.py:275-276 + renderer.py:234) and its backward: g == NULL: out[0] = inv_s;
+// inv_s = exp(10 variance).clip(1e-6, 1e6) (fields.py:275-276 + renderer.py:234) and its backward: g == NULL: out[0] = inv_s, out[1] = 1 / inv_s;
 // else out[0] = g[0] * d inv_s / d variance (10 exp(10 v) inside the clip range, ends included, else 0)
 __global__ void inv_s_kernel(const float* __restrict__ variance, const float* __restrict__ g, float* __restrict__ out) {
   const float e = expf(variance[0] * 10.0f);
-  if (!g) out[0] = fminf(fmaxf(e, 1e-6f), 1e6f);
+  if (!g) { const float v = fminf(fmaxf(e, 1e-6f), 1e6f); out[0] = v; out[1] = 1.0f / v; }      // (out[1]: the logged s_val, renderer.py:288)
   else out[0] = (e >= 1e-6f && e <= 1e6f) ? g[0] * (e * 10.0f) : 0.f;
 }
 extern "C" int avc_inv_s(const float* variance, const float* g, float* out, void* stream) {

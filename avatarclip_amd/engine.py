@@ -283,7 +283,19 @@ class Engine:
 
     # ------------------------------------------------------------------ packing
     def pack(self, flatP: torch.Tensor) -> Packed:
-        return Packed(self.dl, flatP)
+        # (render() packs for the up-sampling passes and RenderCoreFn packs the same vector again: one launch instead of two)
+        last = getattr(self, "_last_pack", None)
+        if last is not None and last[0] is flatP and last[1] == flatP._version:
+            return last[2]
+        pk = Packed(self.dl, flatP)
+        self._last_pack = (flatP, flatP._version, pk)
+        return pk
+
+    def colsum_scratch(self):
+        """the per-workgroup sums + ticket word of avc_colsum (zeroed once; calls are stream-ordered, one stream per engine)"""
+        if getattr(self, "_colsum_scratch", None) is None:
+            self._colsum_scratch = torch.zeros(self.lib.avc_colsum_scratch_bytes(), dtype=torch.uint8, device=self.device)
+        return self._colsum_scratch
 
     def _grow(self, attr, nbytes, dtype=torch.uint8):
         buf = getattr(self, attr)
@@ -597,7 +609,7 @@ class RenderCoreFn(torch.autograd.Function):
             sdf, nrm, rgb, z_vals, rays_o, rays_d, inv_s_d, sample_dist, cos_anneal, bg, bg_mode)
         wsum, wmax = wstat[0].reshape(R, 1), wstat[1].reshape(R, 1)       # (planar: views, no copies)
         eo = torch.empty(2, device=eik.device, dtype=torch.float32)        # renderer.py:283-285 in one launch: (gradient_error, its denominator)
-        L.check(eng.lib.avc_colsum(L.ptr(eik), R, 2, 1, L.ptr(eo), L.stream()), "avc_colsum")
+        L.check(eng.lib.avc_colsum(L.ptr(eik), R, 2, 1, L.ptr(eo), L.ptr(eng.colsum_scratch()), L.stream()), "avc_colsum")
         gerr, eik_den = eo[0], eo[1]
         ctx.eng, ctx.pk = eng, pk
         ctx.consts = (sample_dist, cos_anneal, bg_mode)
@@ -635,5 +647,5 @@ class RenderCoreFn(torch.autograd.Function):
         valid = ctx.panel_token is not None and eng._panel_owner is ctx.panel_token
         grad = eng.points_bwd(pk, rays_o, rays_d, z_vals, sample_dist, d_sdf, d_n, d_rgb, rgb, panels_valid=valid)
         d_inv_s = torch.empty(1, device=d_inv.device, dtype=torch.float32)
-        L.check(eng.lib.avc_colsum(L.ptr(d_inv), R, 1, 0, L.ptr(d_inv_s), L.stream()), "avc_colsum")
+        L.check(eng.lib.avc_colsum(L.ptr(d_inv), R, 1, 0, L.ptr(d_inv_s), L.ptr(eng.colsum_scratch()), L.stream()), "avc_colsum")
         return grad, d_inv_s, None, None, None, None, None, None, None, None

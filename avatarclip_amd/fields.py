@@ -180,9 +180,15 @@ class SingleVarianceNetwork(nn.Module):
     def inv_s(self):
         """exp(10 v).clip(1e-6, 1e6) as a 1-element tensor (fields.py:275-276 + renderer.py:234); on the GPU one launch each way
         (csrc/avc_rays.hip inv_s_kernel) instead of three forward and seven backward."""
+        return self.inv_s_and_s_val()[0]
+
+    def inv_s_and_s_val(self):
+        """(inv_s [1], differentiable; s_val = 1 / inv_s [1,1], detached: the statistic of renderer.py:288 / main.py:546)"""
         if self.variance.is_cuda:
-            return _InvSFn.apply(self.variance)
-        return torch.exp(self.variance * 10.0).clip(1e-6, 1e6).reshape(1)
+            both = _InvSFn.apply(self.variance)
+            return both[:1], both.detach()[1:2].reshape(1, 1)
+        inv_s = torch.exp(self.variance * 10.0).clip(1e-6, 1e6).reshape(1)
+        return inv_s, 1.0 / inv_s.detach().reshape(1, 1)
 
 
 class _InvSFn(torch.autograd.Function):
@@ -190,7 +196,7 @@ class _InvSFn(torch.autograd.Function):
     def forward(ctx, variance):
         from . import lib as L
         v = variance.detach().float().reshape(1).contiguous()
-        out = torch.empty(1, device=v.device, dtype=torch.float32)
+        out = torch.empty(2, device=v.device, dtype=torch.float32)       # (inv_s, 1 / inv_s)
         L.check(L.load().avc_inv_s(L.ptr(v), None, L.ptr(out), L.stream()), "avc_inv_s")
         ctx.save_for_backward(v)
         ctx.shape = variance.shape
@@ -200,7 +206,7 @@ class _InvSFn(torch.autograd.Function):
     def backward(ctx, g):
         from . import lib as L
         (v,) = ctx.saved_tensors
-        g = g.float().reshape(1).contiguous()
+        g = g.float()[:1].contiguous()        # (the second entry, 1 / inv_s, is a detached statistic)
         out = torch.empty(1, device=v.device, dtype=torch.float32)
         L.check(L.load().avc_inv_s(L.ptr(v), L.ptr(g), L.ptr(out), L.stream()), "avc_inv_s")
         return out.reshape(ctx.shape)

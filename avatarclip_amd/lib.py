@@ -45,6 +45,7 @@ _SIGS = {
     "avc_probe_mfma": (c_int, [P, P, P, P, P, P, P]),
     "avc_rasterize_faces": (c_int, [P, P, c_int, c_int, c_float, c_float, P, P, P]),
     "avc_rasterize_scratch_bytes": (c_long, [c_int, c_int]),
+    "avc_rasterize_mesh": (c_int, [P, c_int, P, c_int, P, c_float, P, c_int, c_float, c_float, P, P, c_int, c_int, P, P]),
     "avc_dense_params_fwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P]),
     "avc_dense_params_bwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P]),
     "avc_weight_grad_all": (c_int, [P, c_int, P, c_int, c_int, P, c_long, P, P, c_int, c_int, c_int, P]),
@@ -52,7 +53,8 @@ _SIGS = {
     "avc_weight_grad_unpack": (c_int, [P, P, P, P, c_int, P, P]),
     "avc_shade_loss_blocks": (c_int, [c_int]),
     "avc_shade_loss_fwd": (c_int, [P, P, P, P, P, P, P, P, c_float, P, c_int, c_int, P, P, P, P, P]),
-    "avc_colsum": (c_int, [P, c_long, c_int, c_int, P, P]),
+    "avc_colsum": (c_int, [P, c_long, c_int, c_int, P, P, P]),
+    "avc_colsum_scratch_bytes": (c_long, []),
     "avc_inv_s": (c_int, [P, P, P, P]),
     "avc_pack_params": (c_int, [P, c_int, P, P, c_int, P, P, c_int, P, P, P, P]),
     "avc_coarse_z": (c_int, [P, P, P, c_int, c_int, P, P]),

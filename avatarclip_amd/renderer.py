@@ -85,7 +85,7 @@ class NeuSRenderer:
         eng = self.engine
         if flatP is None:
             flatP = self.flat_params()
-        inv_s = self.deviation_network.inv_s()
+        inv_s, s_val = self.deviation_network.inv_s_and_s_val()
         R, S = z_vals.shape
         bg, bg_mode = None, 0
         if background_rgb is not None and self.extra_color:
@@ -104,7 +104,7 @@ class NeuSRenderer:
             if background_rgb is not None:  # renderer.py:280-281
                 color = color + background_rgb.to(color.device) * (1.0 - wsum)
         return {"color": color, "extra_color": extra, "sdf": sdf.reshape(-1, 1), "gradients": gradients,
-                "s_val": 1.0 / inv_s.detach().reshape(1, 1), "mid_z_vals": mid_z, "weights": weights, "cdf": cdf,
+                "s_val": s_val, "mid_z_vals": mid_z, "weights": weights, "cdf": cdf,
                 "gradient_error": gerr, "inside_sphere": inside, "weight_sum": wsum, "weight_max": wmax, "weighted_normals": nsum}
 
     def render(self, rays_o, rays_d, near, far, perturb_overwrite=-1, background_rgb=None, cos_anneal_ratio=0.0,

@@ -402,7 +402,7 @@ class Runner:
                 ray_of_pixel[sel_idx] = torch.arange(sel_idx.numel(), dtype=torch.int32, device=dev)
             return types.SimpleNamespace(eye=eye, at=at, theta=theta, phi=phi, is_front=is_front, pose=pose, H=H, W=W,
                                          rays_o=rays_o, rays_d=rays_d, near=near, far=far, true_rgb=true_rgb, mask=mask,
-                                         dilated_mask=dilated_mask, sel_idx=sel_idx, ray_of_pixel=ray_of_pixel)
+                                         dilated_mask=dilated_mask, sel_idx=sel_idx, ray_of_pixel=ray_of_pixel, mask_binary=True)
         ori_mask = (true_rgb != 0).float()[..., 0]
         dilated_mask = sel_idx = None
         if self.use_silhouettes:
@@ -426,7 +426,7 @@ class Runner:
             ray_of_pixel[sel_idx] = torch.arange(sel_idx.numel(), dtype=torch.int32, device=dev)
         return types.SimpleNamespace(eye=eye, at=at, theta=theta, phi=phi, is_front=is_front, pose=pose, H=H, W=W,
                                      rays_o=rays_o, rays_d=rays_d, near=near, far=far, true_rgb=true_rgb, mask=mask,
-                                     dilated_mask=dilated_mask, sel_idx=sel_idx, ray_of_pixel=ray_of_pixel)
+                                     dilated_mask=dilated_mask, sel_idx=sel_idx, ray_of_pixel=ray_of_pixel, mask_binary=True)
 
     def _take_view(self, iter_i, camera=None):
         """the view of this iteration: the one prefetch_view prepared, or a fresh one (silhouette mode: on the side stream)"""
@@ -644,7 +644,10 @@ class Runner:
                 bg_const = 1.0
             elif choice_i in (1, 2):
                 bg = background_rgb.reshape(-1)
-        mask = (view.mask > 0.5).float() if self.mask_weight > 0.0 else torch.ones_like(view.mask)
+        if self.mask_weight > 0.0:      # main.py:489: (mask > 0.5).float() -- the identity on the 0 / 1 masks make_view produces
+            mask = view.mask if getattr(view, "mask_binary", False) else (view.mask > 0.5).float()
+        else:
+            mask = torch.ones_like(view.mask)
         images, sums = glue.ShadeLossFn.apply(
             render_out["color_fine"], render_out["extra_color_fine"], render_out["weight_sum"].reshape(-1), nsum, view.true_rgb,
             mask.reshape(-1), rop, bg, bg_const, light4, not self.texture_cast_light)
@@ -664,7 +667,7 @@ class Runner:
         # main.py:491-534 from here on (colour / mask normalisation, the cosines, the weighted sum) in one launch: glue.LossTailFn
         loss, st = glue.LossTailFn.apply(enc_both, text, sums, eikonal_loss, self.igr_weight, self.mask_weight, self.clip_weight, P)
         return loss, dict(color=st[1], eikonal=eikonal_loss, mask=st[2], cosine=st[3], cosine_shading=st[4] if self.add_no_texture else None,
-                          psnr=psnr, s_val=render_out["s_val"][:1].mean()), images
+                          psnr=psnr, s_val=render_out["s_val"][0, 0]), images
 
     def clip_loss(self, iter_i, camera=None):
         """main.py:348-534: one view from camera to scalar loss (differentiable)."""

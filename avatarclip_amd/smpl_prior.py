@@ -12,6 +12,9 @@ import torch
 from . import lib as L
 from . import h2d
 
+import os
+FUSED_PRIOR = os.environ.get("AVC_FUSED_PRIOR", "1") != "0"    # projection + rasteriser + pooling as four launches (0: torch ops around avc_rasterize_faces)
+
 ROT_MAT = ((1.0, 0.0, 0.0), (0.0, 0.0, -1.0), (0.0, 1.0, 0.0))    # models/utils.py:114-118
 
 
@@ -52,7 +55,7 @@ class MeshPrior:
         self.light2 = torch.cat([light_ambient + light_directional * c.clamp(min=0),
                                  light_ambient + light_directional * (-c).clamp(min=0)]).contiguous()
         self.lib = L.load()
-        self._zbuf = None
+        self._zbuf = self._ndc = None
 
     @classmethod
     def from_obj(cls, path, **kw):
@@ -72,7 +75,7 @@ class MeshPrior:
         return cls(verts[0].detach().cpu().numpy(), smpl["faces"], **kw)
 
     @torch.no_grad()
-    def render_grey(self, eye, direction):
+    def render_grey(self, eye, direction, rgb_flipped=False):
         """nr.Renderer(camera_mode='look')(vertices, faces, ones) -> [S,S] grey image (before the x flip)"""
         dev = self.device
         # neural_renderer/look.py: the camera frame, in float32 like there -- on the host (a dozen small launches otherwise), one upload
@@ -84,6 +87,20 @@ class MeshPrior:
         y = np.cross(z, x).astype(f)
         y = y / f(np.sqrt((y * y).sum(dtype=f)))
         cam = h2d.upload(np.concatenate([np.asarray(eye, f), x, y, z]), dev)
+        S = self.image_size
+        if FUSED_PRIOR:      # projection + rasteriser + 2 x 2 average (+ x flip + channels) in four launches (csrc/avc_raster.hip)
+            ch = 3 if rgb_flipped else 1
+            out = torch.empty((S, S, 3) if rgb_flipped else (S, S), device=dev, dtype=torch.float32)
+            need = self.lib.avc_rasterize_scratch_bytes(self.faces2.shape[0], 2 * S)
+            if self._zbuf is None or self._zbuf.numel() != need:
+                self._zbuf = torch.full((need,), 255, dtype=torch.uint8, device=dev)
+            if self._ndc is None:
+                self._ndc = torch.empty_like(self.v_world)
+                self._faces2_i32 = self.faces2.to(torch.int32).contiguous()
+            L.check(self.lib.avc_rasterize_mesh(L.ptr(self.v_world), self.v_world.shape[0], L.ptr(self._faces2_i32), self.faces2.shape[0], L.ptr(cam),
+                                                self.width, L.ptr(self.light2), S, self.near, self.far, L.ptr(self._ndc), L.ptr(out),
+                                                int(rgb_flipped), ch, L.ptr(self._zbuf), L.stream()), "avc_rasterize_mesh")
+            return out
         v = (self.v_world - cam[:3]) @ cam[3:].reshape(3, 3).t()
         ndc = torch.stack([v[:, 0] / v[:, 2] / self.width, v[:, 1] / v[:, 2] / self.width, v[:, 2]], dim=1)   # perspective.py
         fz = ndc[self.faces2].reshape(-1, 9).contiguous()
@@ -94,9 +111,10 @@ class MeshPrior:
             self._zbuf = torch.full((need,), 255, dtype=torch.uint8, device=dev)
         L.check(self.lib.avc_rasterize_faces(L.ptr(fz), L.ptr(self.light2), fz.shape[0], S2, self.near, self.far, L.ptr(img),
                                              L.ptr(self._zbuf), L.stream()), "avc_rasterize_faces")
-        return torch.nn.functional.avg_pool2d(img[None, None], kernel_size=2, stride=2)[0, 0]
+        grey = torch.nn.functional.avg_pool2d(img[None, None], kernel_size=2, stride=2)[0, 0]
+        return grey.flip(1)[..., None].repeat(1, 1, 3) if rgb_flipped else grey
 
     def __call__(self, eye, at):
         eye, at = np.asarray(eye, np.float64), np.asarray(at, np.float64)
-        grey = self.render_grey(eye, (at - eye) / np.linalg.norm(at - eye))
-        return grey.flip(1)[..., None].repeat(1, 1, 3)              # models/utils.py:124 (`[:, ::-1]`), white texture: R = G = B
+        # models/utils.py:124 (`[:, ::-1]`), white texture: R = G = B
+        return self.render_grey(eye, (at - eye) / np.linalg.norm(at - eye), rgb_flipped=True)

@@ -66,8 +66,10 @@ int avc_composite_fwd(const float* sdf, const float* normal, const float* rgb, c
 
 /* The scalar reductions around the compositing kernels in one launch each: column sums of x [R,C] (C <= 4) in a fixed order; mode 1
  * (x = avc_composite_fwd's eik): out[1] = sum x[:,1] + 1e-5, out[0] = sum x[:,0] / out[1] = the eikonal term of renderer.py:283-285.
- * avc_inv_s: out[0] = exp(10 variance).clip(1e-6, 1e6) (fields.py:275-276, renderer.py:234); with g != NULL its backward g[0] * d/dv. */
-int avc_colsum(const float* x, long R, int C, int mode, float* out, void* stream);
+ * avc_inv_s: out[0] = exp(10 variance).clip(1e-6, 1e6), out[1] = 1 / out[0] (fields.py:275-276, renderer.py:234,288); with g != NULL:
+ * out[0] = its backward g[0] * d/dv. */
+long avc_colsum_scratch_bytes(void);   /* zero-initialised once by the caller; every call leaves its ticket word zero */
+int avc_colsum(const float* x, long R, int C, int mode, float* out, void* scratch, void* stream);
 int avc_inv_s(const float* variance, const float* g, float* out, void* stream);
 
 /* Reverse of avc_composite_fwd.  Upstream: d_color[R,3], d_extra[R,3], d_weights[R,S] (may be NULL), d_normal_up[R,S,3] (may
@@ -295,6 +297,12 @@ int avc_probe_mfma(const void* a_f16, const void* b_f16, float* d, const void* a
  * z-buffer of 64-bit (depth bits, face index) keys the faces race into with atomicMin + the list of the faces too large for that
  * (handled tile by tile) -- avc_rasterize_scratch_bytes(F, image_size) bytes that the caller fills with 0xFF once; every call hands
  * them back that way. */
+/* The same from the world-space mesh in four launches (projection look.py / perspective.py -> rasteriser at the 2 x super-sampled size on
+ * faces gathered through idx [F,3] -> 2 x 2 average, optional x flip (models/utils.py:124) and three equal channels): v_world [V,3], cam =
+ * device [12] (eye, x / y / z axis of the look frame), width = tan(viewing angle); ndc [V,3] scratch; out [S,S] or [S,S,3];
+ * scratch: avc_rasterize_scratch_bytes(F, 2 S). */
+int avc_rasterize_mesh(const float* v_world, int V, const int* idx, int F, const float* cam, float width, const float* light, int S,
+                       float near_, float far_, float* ndc, float* out, int flip_x, int channels, void* scratch, void* stream);
 long avc_rasterize_scratch_bytes(int F, int image_size);
 int avc_rasterize_faces(const float* faces, const float* light, int F, int image_size, float near_, float far_,
                         float* image, void* scratch /* avc_rasterize_scratch_bytes, 0xFF-filled on entry; left so */, void* stream);

@@ -352,7 +352,8 @@ def test_head_fusions_equal_their_torch_statements(monkeypatch):
         assert zs[0].shape == (R, ren.n_samples) and torch.equal(zs[0], zs[1]), (perturb, (zs[0] - zs[1]).abs().max())
     for v0 in (0.3, 0.05, -1.5, 1.45):       # (-1.5 and 1.45: outside the clip range -> zero gradient)
         net = fields.SingleVarianceNetwork(v0).to(dev)
-        y = net.inv_s()
+        y, sv = net.inv_s_and_s_val()
+        assert torch.allclose(sv.reshape(1), 1.0 / y.detach(), rtol=1e-6)
         (y * 1.7).sum().backward()
         vr = torch.tensor(v0, device=dev, requires_grad=True)
         yr = torch.exp(vr * 10.0).clip(1e-6, 1e6).reshape(1)
@@ -360,8 +361,9 @@ def test_head_fusions_equal_their_torch_statements(monkeypatch):
         assert torch.allclose(y.detach(), yr.detach(), rtol=2e-6) and torch.allclose(net.variance.grad, vr.grad, rtol=2e-6), (v0, y, yr)
     x = torch.rand(100003, 2, generator=g).to(dev)
     out = torch.empty(2, device=dev)
-    L.check(lib.avc_colsum(L.ptr(x), x.shape[0], 2, 1, L.ptr(out), L.stream()), "colsum")
+    scr = torch.zeros(lib.avc_colsum_scratch_bytes(), dtype=torch.uint8, device=dev)
+    L.check(lib.avc_colsum(L.ptr(x), x.shape[0], 2, 1, L.ptr(out), L.ptr(scr), L.stream()), "colsum")
     den = x[:, 1].double().sum() + 1e-5
     assert abs(out[1].item() - den.item()) < 1e-5 * den.item() and abs(out[0].item() - (x[:, 0].double().sum() / den).item()) < 1e-5
-    L.check(lib.avc_colsum(L.ptr(x), x.shape[0], 2, 0, L.ptr(out), L.stream()), "colsum")
+    L.check(lib.avc_colsum(L.ptr(x), x.shape[0], 2, 0, L.ptr(out), L.ptr(scr), L.stream()), "colsum")
     assert torch.allclose(out.double(), x.double().sum(0), rtol=1e-5)

@@ -75,8 +75,17 @@ def test_hip_rasteriser_matches_restatement():
             # close-ups: faces whose boxes hold thousands of sub-pixels (the tile-parallel pass of the rasteriser), the second one
             # from so near that part of the body is beside / behind the camera
             (np.array([0.05, 0.35, 0.55]), np.array([0.0, 0.3, 0.0])), (np.array([0.1, 0.0, 0.22]), np.array([0.0, 0.1, 0.0]))]
+    import avatarclip_amd.smpl_prior as SP
     for eye, at in cams:
+        # the four-launch form (projection + pooling inside the library) against the torch ops around avc_rasterize_faces: same image up to
+        # the few sub-pixels whose edge test sits within an ulp of the projection's rounding
+        SP.FUSED_PRIOR = False
+        unf = prior(eye, at).cpu().numpy()
+        SP.FUSED_PRIOR = True
         out = prior(eye, at).cpu().numpy()
+        nd = (np.abs(out[..., 0] - unf[..., 0]) > 1e-6).sum()
+        assert nd <= 24 and np.abs(out - unf).max() <= 0.51, (nd, np.abs(out - unf).max())     # (13 of 65 536 pixels on the nearest close-up, 0 on the far views)
+        assert np.array_equal(prior.render_grey(eye, (at - eye) / np.linalg.norm(at - eye)).cpu().numpy()[:, ::-1], out[..., 0])
         ref = NR.render_one_batch(V.astype(np.float64), Fc, eye, at).astype(np.float32)
         assert out.shape == (256, 256, 3) and np.array_equal(out[..., 0], out[..., 1])
         mism = ((out[..., 0] > 0) != (ref[..., 0] > 0)).sum()

@@ -154,13 +154,146 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
   }
 }
 
+// The same step for n + m <= 64 (the reference's 64-spp confs: n = 32 .. 56, m = 8): FOUR rays per wavefront, 16 lanes per ray, a lane
+// owns every 16th sample in the elementwise phases and a contiguous chunk of <= 4 in the scans.  With one ray per wavefront most of a
+// step's ~600 instructions are scan / search / synchronisation overhead executed for 32-56 live lanes (8 in the inversion); a 16-lane
+// group pays that overhead once for its ray and the wavefront carries four of them (profiles/r04_ab_kernels.txt).
+#define U16_S 64
+#define U16_RPB 16        // rays per 256-thread block
+__device__ __forceinline__ float grp_incl_scan_mul(float v, int gl) {
+#pragma unroll
+  for (int d = 1; d < 16; d <<= 1) { const float o = __shfl_up(v, d, 16); if (gl >= d) v *= o; }
+  return v;
+}
+__device__ __forceinline__ float grp_incl_scan_add(float v, int gl) {
+#pragma unroll
+  for (int d = 1; d < 16; d <<= 1) { const float o = __shfl_up(v, d, 16); if (gl >= d) v += o; }
+  return v;
+}
+__device__ __forceinline__ float grp_sum(float v) {
+#pragma unroll
+  for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+__global__ __launch_bounds__(256) void upsample16_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                         const float* __restrict__ z_in, const float* __restrict__ sdf_in,
+                                                         int R, int n, int m, float inv_s, float* __restrict__ z_out,
+                                                         float* __restrict__ sdf_out, float* __restrict__ z_new,
+                                                         int* __restrict__ slot_new) {
+  __shared__ float sz[U16_RPB][U16_S], ss[U16_RPB][U16_S], sa[U16_RPB][U16_S], sc[U16_RPB][U16_S], sn[U16_RPB][16];
+  const int lane = threadIdx.x & 63, gl = lane & 15;
+  const int slot = (threadIdx.x >> 6) * 4 + (lane >> 4);
+  // (groups past the last ray redo ray R - 1 without storing)
+  const bool active = (long)blockIdx.x * U16_RPB + slot < R;
+  const int ray = active ? blockIdx.x * U16_RPB + slot : R - 1;
+  float* Z = sz[slot]; float* Sd = ss[slot]; float* A = sa[slot]; float* C = sc[slot]; float* NZ = sn[slot];
+  const float ox = rays_o[3 * ray], oy = rays_o[3 * ray + 1], oz = rays_o[3 * ray + 2];
+  const float dx = rays_d[3 * ray], dy = rays_d[3 * ray + 1], dz = rays_d[3 * ray + 2];
+  for (int i = gl; i < n; i += 16) { Z[i] = z_in[(long)ray * n + i]; Sd[i] = sdf_in[(long)ray * n + i]; }
+  WAVE_SYNC();
+  const int nm1 = n - 1;
+  for (int i = gl; i < nm1; i += 16) C[i] = (Sd[i + 1] - Sd[i]) / (Z[i + 1] - Z[i] + 1e-5f);
+  WAVE_SYNC();
+  for (int i = gl; i < nm1; i += 16) {
+    const float z0 = Z[i], z1 = Z[i + 1];
+    const float px0 = ox + dx * z0, py0 = oy + dy * z0, pz0 = oz + dz * z0;
+    const float px1 = ox + dx * z1, py1 = oy + dy * z1, pz1 = oz + dz * z1;
+    const float r0 = sqrtf(px0 * px0 + py0 * py0 + pz0 * pz0), r1 = sqrtf(px1 * px1 + py1 * py1 + pz1 * pz1);
+    const float inside = (r0 < 1.0f || r1 < 1.0f) ? 1.f : 0.f;
+    const float prev = (i == 0) ? 0.f : C[i - 1];
+    float cv = fminf(prev, C[i]);
+    cv = fminf(fmaxf(cv, -1e3f), 0.f) * inside;
+    const float mid = (Sd[i] + Sd[i + 1]) * 0.5f;
+    const float dist = z1 - z0;
+    const float pe = mid - cv * dist * 0.5f, ne = mid + cv * dist * 0.5f;
+    const float pc = sigmoidf_(pe * inv_s), nc = sigmoidf_(ne * inv_s);
+    A[i] = (pc - nc + 1e-5f) / (pc + 1e-5f);
+  }
+  WAVE_SYNC();
+  // transmittance: exclusive cumprod of (1 - alpha + 1e-7) -> C; a lane owns the `per` consecutive entries from gl * per
+  const int per = (nm1 + 15) / 16;
+  const int b = gl * per;
+  {
+    float loc = 1.f;
+    for (int k = 0; k < per; ++k) if (b + k < nm1) loc *= 1.f - A[b + k] + 1e-7f;
+    const float inc = grp_incl_scan_mul(loc, gl);
+    float run = __shfl_up(inc, 1, 16);
+    if (gl == 0) run = 1.f;
+    for (int k = 0; k < per; ++k)
+      if (b + k < nm1) { C[b + k] = run; run *= 1.f - A[b + k] + 1e-7f; }
+  }
+  WAVE_SYNC();
+  // weights + 1e-5, pdf, cdf (sample_pdf, renderer.py:42-45)
+  float loc = 0.f;
+  for (int i = gl; i < nm1; i += 16) { const float wv = A[i] * C[i] + 1e-5f; A[i] = wv; loc += wv; }
+  const float tot = grp_sum(loc);
+  WAVE_SYNC();
+  {
+    float s = 0.f;
+    for (int k = 0; k < per; ++k) if (b + k < nm1) s += A[b + k] / tot;
+    const float inc = grp_incl_scan_add(s, gl);
+    float run = __shfl_up(inc, 1, 16);
+    if (gl == 0) run = 0.f;
+    for (int k = 0; k < per; ++k)
+      if (b + k < nm1) { run += A[b + k] / tot; A[b + k] = run; }
+  }
+  WAVE_SYNC();
+  // cdf = [0, A[0..nm1-1]] has n entries; invert at the m deterministic u's (torch.linspace semantics)
+  if (gl < m) {
+    const float start = 0.5f / m, end = 1.f - 0.5f / m;
+    const float step = (m > 1) ? (end - start) / (float)(m - 1) : 0.f;
+    const float u = (gl < m / 2) ? start + step * gl : end - step * (m - 1 - gl);
+    int lo = 0, hi = n;
+    while (lo < hi) {
+      const int midi = (lo + hi) >> 1;
+      const float cv = (midi == 0) ? 0.f : A[midi - 1];
+      if (cv <= u) lo = midi + 1; else hi = midi;
+    }
+    const int below = max(lo - 1, 0), above = min(lo, n - 1);
+    const float cb = (below == 0) ? 0.f : A[below - 1];
+    const float ca = (above == 0) ? 0.f : A[above - 1];
+    float denom = ca - cb;
+    if (denom < 1e-5f) denom = 1.f;
+    const float t = (u - cb) / denom;
+    NZ[gl] = Z[below] + t * (Z[above] - Z[below]);
+  }
+  WAVE_SYNC();
+  // merge (both lists ascending; ties keep the old sample first, like a stable sort of cat([z, new_z]))
+  float* zo = z_out + (long)ray * (n + m);
+  float* so = sdf_out + (long)ray * (n + m);
+  for (int i = gl; i < n; i += 16) {
+    const float zv = Z[i];
+    int lo = 0, hi = m;  // count new < zv
+    while (lo < hi) { const int k = (lo + hi) >> 1; if (NZ[k] < zv) lo = k + 1; else hi = k; }
+    if (active) { zo[i + lo] = zv; so[i + lo] = Sd[i]; }
+  }
+  if (gl < m) {
+    const float zv = NZ[gl];
+    int lo = 0, hi = n;  // count old <= zv
+    while (lo < hi) { const int k = (lo + hi) >> 1; if (Z[k] <= zv) lo = k + 1; else hi = k; }
+    if (active) {
+      zo[gl + lo] = zv;
+      so[gl + lo] = 0.f;
+      z_new[(long)ray * m + gl] = zv;
+      slot_new[(long)ray * m + gl] = gl + lo;
+    }
+  }
+}
+#ifndef AVC_UPSAMPLE16
+#define AVC_UPSAMPLE16 1   // 0: one wavefront per ray for every n (the A/B partner)
+#endif
+
 extern "C" int avc_upsample_step(const float* rays_o, const float* rays_d, const float* z_in, const float* sdf_in,
                                  int R, int n, int m, float inv_s, float* z_out, float* sdf_out, float* z_new,
                                  int* slot_new, void* stream) {
   if (n > MAXS || m > 64 || n + m > MAXS || n < 2) { avc_set_error("avc_upsample_step: need 2 <= n, n+m <= 256, m <= 64"); return 1; }
   if (R <= 0) return 0;
-  hipLaunchKernelGGL(upsample_kernel, dim3((R + RPB - 1) / RPB), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, z_in,
-                     sdf_in, R, n, m, inv_s, z_out, sdf_out, z_new, slot_new);
+  if (AVC_UPSAMPLE16 && n + m <= U16_S && m <= 16)
+    hipLaunchKernelGGL(upsample16_kernel, dim3((R + U16_RPB - 1) / U16_RPB), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, z_in,
+                       sdf_in, R, n, m, inv_s, z_out, sdf_out, z_new, slot_new);
+  else
+    hipLaunchKernelGGL(upsample_kernel, dim3((R + RPB - 1) / RPB), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, z_in,
+                       sdf_in, R, n, m, inv_s, z_out, sdf_out, z_new, slot_new);
   return avc_check_launch("avc_upsample_step");
 }
 

@@ -285,10 +285,10 @@ class Engine:
     def pack(self, flatP: torch.Tensor) -> Packed:
         # (render() packs for the up-sampling passes and RenderCoreFn packs the same vector again: one launch instead of two)
         last = getattr(self, "_last_pack", None)
-        if last is not None and last[0] is flatP and last[1] == flatP._version:
+        if last is not None and last[0]() is flatP and last[1] == flatP._version:
             return last[2]
         pk = Packed(self.dl, flatP)
-        self._last_pack = (flatP, flatP._version, pk)
+        self._last_pack = (weakref.ref(flatP), flatP._version, pk)     # (weak: the vector carries last iteration's autograd graph)
         return pk
 
     def colsum_scratch(self):

@@ -3,6 +3,7 @@
 //   avc_upsample_step   renderer.py:133-177 (up_sample) + :39-69 (sample_pdf, det=True) + :179-193 (cat_z_vals merge)
 //   avc_composite_fwd   renderer.py:234-286 (alpha, transmittance, colours, eikonal partials)
 //   avc_composite_bwd   its reverse
+#include <cstdlib>
 #include "avc_common.h"
 #include "../../include/avc.h"
 
@@ -154,47 +155,51 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
   }
 }
 
-// The same step for n + m <= 64 (the reference's 64-spp confs: n = 32 .. 56, m = 8): FOUR rays per wavefront, 16 lanes per ray, a lane
-// owns every 16th sample in the elementwise phases and a contiguous chunk of <= 4 in the scans.  With one ray per wavefront most of a
-// step's ~600 instructions are scan / search / synchronisation overhead executed for 32-56 live lanes (8 in the inversion); a 16-lane
-// group pays that overhead once for its ray and the wavefront carries four of them (profiles/r04_ab_kernels.txt).
-#define U16_S 64
-#define U16_RPB 16        // rays per 256-thread block
+// The same step with SEVERAL rays per wavefront: a group of GL lanes per ray (GL = 16 for n + m <= 64, the reference's 64-spp confs:
+// n = 32 .. 56, m = 8 -- four rays per wavefront; GL = 32 for n + m <= 128, the 128-spp conf: two), a lane owns every GL-th sample in
+// the elementwise phases and a contiguous chunk of <= 4 in the scans.  With one ray per wavefront most of a step's ~600 instructions
+// are scan / search / synchronisation overhead executed for 32-56 live lanes (8 in the inversion); a group pays that overhead once for
+// its ray and the wavefront carries four of them (profiles/r04_ab_kernels.txt).
+template <int GL>
 __device__ __forceinline__ float grp_incl_scan_mul(float v, int gl) {
 #pragma unroll
-  for (int d = 1; d < 16; d <<= 1) { const float o = __shfl_up(v, d, 16); if (gl >= d) v *= o; }
+  for (int d = 1; d < GL; d <<= 1) { const float o = __shfl_up(v, d, GL); if (gl >= d) v *= o; }
   return v;
 }
+template <int GL>
 __device__ __forceinline__ float grp_incl_scan_add(float v, int gl) {
 #pragma unroll
-  for (int d = 1; d < 16; d <<= 1) { const float o = __shfl_up(v, d, 16); if (gl >= d) v += o; }
+  for (int d = 1; d < GL; d <<= 1) { const float o = __shfl_up(v, d, GL); if (gl >= d) v += o; }
   return v;
 }
+template <int GL>
 __device__ __forceinline__ float grp_sum(float v) {
 #pragma unroll
-  for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  for (int d = GL / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d);
   return v;
 }
-__global__ __launch_bounds__(256) void upsample16_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+template <int GL>
+__global__ __launch_bounds__(256) void upsample_grp_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                          const float* __restrict__ z_in, const float* __restrict__ sdf_in,
                                                          int R, int n, int m, float inv_s, float* __restrict__ z_out,
                                                          float* __restrict__ sdf_out, float* __restrict__ z_new,
                                                          int* __restrict__ slot_new) {
-  __shared__ float sz[U16_RPB][U16_S], ss[U16_RPB][U16_S], sa[U16_RPB][U16_S], sc[U16_RPB][U16_S], sn[U16_RPB][16];
-  const int lane = threadIdx.x & 63, gl = lane & 15;
-  const int slot = (threadIdx.x >> 6) * 4 + (lane >> 4);
+  constexpr int US = 4 * GL, RPBG = 256 / GL;      // samples a group can hold, rays per 256-thread block
+  __shared__ float sz[RPBG][US], ss[RPBG][US], sa[RPBG][US], sc[RPBG][US], sn[RPBG][16];
+  const int lane = threadIdx.x & 63, gl = lane & (GL - 1);
+  const int slot = (threadIdx.x >> 6) * (64 / GL) + lane / GL;
   // (groups past the last ray redo ray R - 1 without storing)
-  const bool active = (long)blockIdx.x * U16_RPB + slot < R;
-  const int ray = active ? blockIdx.x * U16_RPB + slot : R - 1;
+  const bool active = (long)blockIdx.x * RPBG + slot < R;
+  const int ray = active ? blockIdx.x * RPBG + slot : R - 1;
   float* Z = sz[slot]; float* Sd = ss[slot]; float* A = sa[slot]; float* C = sc[slot]; float* NZ = sn[slot];
   const float ox = rays_o[3 * ray], oy = rays_o[3 * ray + 1], oz = rays_o[3 * ray + 2];
   const float dx = rays_d[3 * ray], dy = rays_d[3 * ray + 1], dz = rays_d[3 * ray + 2];
-  for (int i = gl; i < n; i += 16) { Z[i] = z_in[(long)ray * n + i]; Sd[i] = sdf_in[(long)ray * n + i]; }
+  for (int i = gl; i < n; i += GL) { Z[i] = z_in[(long)ray * n + i]; Sd[i] = sdf_in[(long)ray * n + i]; }
   WAVE_SYNC();
   const int nm1 = n - 1;
-  for (int i = gl; i < nm1; i += 16) C[i] = (Sd[i + 1] - Sd[i]) / (Z[i + 1] - Z[i] + 1e-5f);
+  for (int i = gl; i < nm1; i += GL) C[i] = (Sd[i + 1] - Sd[i]) / (Z[i + 1] - Z[i] + 1e-5f);
   WAVE_SYNC();
-  for (int i = gl; i < nm1; i += 16) {
+  for (int i = gl; i < nm1; i += GL) {
     const float z0 = Z[i], z1 = Z[i + 1];
     const float px0 = ox + dx * z0, py0 = oy + dy * z0, pz0 = oz + dz * z0;
     const float px1 = ox + dx * z1, py1 = oy + dy * z1, pz1 = oz + dz * z1;
@@ -211,13 +216,13 @@ __global__ __launch_bounds__(256) void upsample16_kernel(const float* __restrict
   }
   WAVE_SYNC();
   // transmittance: exclusive cumprod of (1 - alpha + 1e-7) -> C; a lane owns the `per` consecutive entries from gl * per
-  const int per = (nm1 + 15) / 16;
+  const int per = (nm1 + GL - 1) / GL;
   const int b = gl * per;
   {
     float loc = 1.f;
     for (int k = 0; k < per; ++k) if (b + k < nm1) loc *= 1.f - A[b + k] + 1e-7f;
-    const float inc = grp_incl_scan_mul(loc, gl);
-    float run = __shfl_up(inc, 1, 16);
+    const float inc = grp_incl_scan_mul<GL>(loc, gl);
+    float run = __shfl_up(inc, 1, GL);
     if (gl == 0) run = 1.f;
     for (int k = 0; k < per; ++k)
       if (b + k < nm1) { C[b + k] = run; run *= 1.f - A[b + k] + 1e-7f; }
@@ -225,14 +230,14 @@ __global__ __launch_bounds__(256) void upsample16_kernel(const float* __restrict
   WAVE_SYNC();
   // weights + 1e-5, pdf, cdf (sample_pdf, renderer.py:42-45)
   float loc = 0.f;
-  for (int i = gl; i < nm1; i += 16) { const float wv = A[i] * C[i] + 1e-5f; A[i] = wv; loc += wv; }
-  const float tot = grp_sum(loc);
+  for (int i = gl; i < nm1; i += GL) { const float wv = A[i] * C[i] + 1e-5f; A[i] = wv; loc += wv; }
+  const float tot = grp_sum<GL>(loc);
   WAVE_SYNC();
   {
     float s = 0.f;
     for (int k = 0; k < per; ++k) if (b + k < nm1) s += A[b + k] / tot;
-    const float inc = grp_incl_scan_add(s, gl);
-    float run = __shfl_up(inc, 1, 16);
+    const float inc = grp_incl_scan_add<GL>(s, gl);
+    float run = __shfl_up(inc, 1, GL);
     if (gl == 0) run = 0.f;
     for (int k = 0; k < per; ++k)
       if (b + k < nm1) { run += A[b + k] / tot; A[b + k] = run; }
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(256) void upsample16_kernel(const float* __restrict
   // merge (both lists ascending; ties keep the old sample first, like a stable sort of cat([z, new_z]))
   float* zo = z_out + (long)ray * (n + m);
   float* so = sdf_out + (long)ray * (n + m);
-  for (int i = gl; i < n; i += 16) {
+  for (int i = gl; i < n; i += GL) {
     const float zv = Z[i];
     int lo = 0, hi = m;  // count new < zv
     while (lo < hi) { const int k = (lo + hi) >> 1; if (NZ[k] < zv) lo = k + 1; else hi = k; }
@@ -279,18 +284,21 @@ __global__ __launch_bounds__(256) void upsample16_kernel(const float* __restrict
     }
   }
 }
-#ifndef AVC_UPSAMPLE16
-#define AVC_UPSAMPLE16 1   // 0: one wavefront per ray for every n (the A/B partner)
-#endif
 
 extern "C" int avc_upsample_step(const float* rays_o, const float* rays_d, const float* z_in, const float* sdf_in,
                                  int R, int n, int m, float inv_s, float* z_out, float* sdf_out, float* z_new,
                                  int* slot_new, void* stream) {
   if (n > MAXS || m > 64 || n + m > MAXS || n < 2) { avc_set_error("avc_upsample_step: need 2 <= n, n+m <= 256, m <= 64"); return 1; }
   if (R <= 0) return 0;
-  if (AVC_UPSAMPLE16 && n + m <= U16_S && m <= 16)
-    hipLaunchKernelGGL(upsample16_kernel, dim3((R + U16_RPB - 1) / U16_RPB), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, z_in,
-                       sdf_in, R, n, m, inv_s, z_out, sdf_out, z_new, slot_new);
+  // AVC_UPSAMPLE_GROUP=0 in the environment: one wavefront per ray for every n (the A/B partner and the cross-check of the tests)
+  const char* e = getenv("AVC_UPSAMPLE_GROUP");
+  const bool grouped = !(e && e[0] == '0') && m <= 16;
+  if (grouped && n + m <= 64)
+    hipLaunchKernelGGL(upsample_grp_kernel<16>, dim3((R + 15) / 16), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, z_in, sdf_in, R, n, m,
+                       inv_s, z_out, sdf_out, z_new, slot_new);
+  else if (grouped && n + m <= 128)
+    hipLaunchKernelGGL(upsample_grp_kernel<32>, dim3((R + 7) / 8), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, z_in, sdf_in, R, n, m,
+                       inv_s, z_out, sdf_out, z_new, slot_new);
   else
     hipLaunchKernelGGL(upsample_kernel, dim3((R + RPB - 1) / RPB), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, z_in,
                        sdf_in, R, n, m, inv_s, z_out, sdf_out, z_new, slot_new);

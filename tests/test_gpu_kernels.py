@@ -367,3 +367,32 @@ def test_head_fusions_equal_their_torch_statements(monkeypatch):
     assert abs(out[1].item() - den.item()) < 1e-5 * den.item() and abs(out[0].item() - (x[:, 0].double().sum() / den).item()) < 1e-5
     L.check(lib.avc_colsum(L.ptr(x), x.shape[0], 2, 0, L.ptr(out), L.ptr(scr), L.stream()), "colsum")
     assert torch.allclose(out.double(), x.double().sum(0), rtol=1e-5)
+
+
+@gpu
+@pytest.mark.parametrize("n,m", [(32, 8), (56, 8), (47, 5), (64, 16), (112, 16), (120, 8)])
+def test_grouped_upsample_kernel_equals_one_ray_per_wavefront(n, m, monkeypatch):
+    """avc_upsample_step with several rays per wavefront (16 or 32 lanes per ray) against the one-wavefront-per-ray kernel (which
+    the golden records of the reference pin, test_upsample_steps_match_reference): same algorithm, the scans add / multiply in a
+    different order -> new depths equal to ~1e-6 except where the inversion lands on a bin edge; the merge invariants hold exactly."""
+    from avatarclip_amd import engine, packing as PK
+    dev = torch.device("cuda")
+    eng = engine.Engine(PK.SMALL, dev)
+    g = torch.Generator().manual_seed(n * 100 + m)
+    R = 1003
+    ro = (torch.randn(R, 3, generator=g) * 0.2).to(dev)
+    rd = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1).to(dev)
+    z = torch.sort(torch.rand(R, n, generator=g) * 2 + 0.2, dim=-1)[0].to(dev).contiguous()
+    pts = ro[:, None, :] + rd[:, None, :] * z[..., None]
+    sdf = (pts.norm(dim=-1) - 0.6 + 0.02 * torch.randn(R, n, generator=g).to(dev)).contiguous()     # a noisy sphere: surface crossings
+    outs = []
+    for grouped in ("1", "0"):
+        monkeypatch.setenv("AVC_UPSAMPLE_GROUP", grouped)
+        outs.append(eng.upsample_step(ro, rd, z, sdf, m, 64.0))
+    (za, sa, na, sla), (zb, sb, nb_, slb) = outs
+    err = (na - nb_).abs()
+    assert err.median() < 2e-6 and (err > 1e-3).float().mean() < 5e-3, (err.median().item(), err.max().item())
+    zs, _ = torch.sort(torch.cat([z, na], -1), dim=-1)
+    assert torch.equal(zs, za) and torch.equal(torch.gather(za, 1, sla.long()), na)
+    keep = torch.ones_like(za, dtype=torch.bool).scatter_(1, sla.long(), False)
+    assert torch.equal(sa[keep].reshape(z.shape), sdf)

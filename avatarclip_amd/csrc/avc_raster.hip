@@ -81,7 +81,7 @@ __device__ __forceinline__ void load_face(const float* __restrict__ faces, const
   }
 }
 // neural_renderer's look + perspective (look.py, perspective.py; models/utils.py:108-125): v_cam = (v - eye) . (x, y, z axes),
-// ndc = (x / z / width, y / z / width, z); cam = device [12]: eye, x axis, y axis, z axis
+// ndc = (x / z / width, y / z / width, z), (0, 0, 0) for z <= 0; cam = device [12]: eye, x axis, y axis, z axis
 __global__ __launch_bounds__(256) void prior_project_kernel(const float* __restrict__ vw, int V, const float* __restrict__ cam, float width,
                                                             float* __restrict__ ndc) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -90,9 +90,10 @@ __global__ __launch_bounds__(256) void prior_project_kernel(const float* __restr
   float c[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) c[j] = fmaf(d2, cam[3 + 3 * j + 2], fmaf(d1, cam[3 + 3 * j + 1], d0 * cam[3 + 3 * j]));
-  ndc[3 * i] = c[0] / c[2] / width;
-  ndc[3 * i + 1] = c[1] / c[2] / width;
-  ndc[3 * i + 2] = c[2];
+  const bool behind = c[2] <= 0.f;      // the patch the reference's README.md:126-134 prescribes for perspective.py: behind the camera -> (0, 0, 0)
+  ndc[3 * i] = behind ? 0.f : c[0] / c[2] / width;
+  ndc[3 * i + 1] = behind ? 0.f : c[1] / c[2] / width;
+  ndc[3 * i + 2] = behind ? 0.f : c[2];
 }
 // `large` = [count - 1 (0xFFFFFFFF = none), face indices ...]
 __global__ __launch_bounds__(256) void raster_faces_kernel(const float* __restrict__ faces /* [F,9] x,y (NDC), z (depth) */,

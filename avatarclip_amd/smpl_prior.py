@@ -103,6 +103,7 @@ class MeshPrior:
             return out
         v = (self.v_world - cam[:3]) @ cam[3:].reshape(3, 3).t()
         ndc = torch.stack([v[:, 0] / v[:, 2] / self.width, v[:, 1] / v[:, 2] / self.width, v[:, 2]], dim=1)   # perspective.py
+        ndc = torch.where(v[:, 2:3] <= 0, torch.zeros_like(ndc), ndc)     # ... with the reference's patch (README.md:126-134): behind the camera -> 0
         fz = ndc[self.faces2].reshape(-1, 9).contiguous()
         S2 = 2 * self.image_size                                    # anti_aliasing=True
         img = torch.empty(S2, S2, device=dev, dtype=torch.float32)

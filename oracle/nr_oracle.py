@@ -7,7 +7,8 @@ renders: camera_mode='look_at').  Published algorithm restated here (neural_rend
 lighting,rasterize}.py and cuda/rasterize_cuda_kernel.cu of the PyTorch port):
 
   Renderer defaults: image_size 256, anti_aliasing True (rasterise at 2x, then 2x2 average pool), fill_back True (every face
-  also in reversed order), perspective with viewing_angle 30 deg (x' = x / z / tan 30), near 0.1, far 100, background 0,
+  also in reversed order), perspective with viewing_angle 30 deg (x' = x / z / tan 30; vertices with z <= 0 -> (0, 0, 0): the patch of
+  the reference's README.md:126-134), near 0.1, far 100, background 0,
   light = ambient 0.5 + directional 0.5 * relu(n . (0,1,0)) with the FACE normal n = normalize((v0 - v1) x (v2 - v1)) taken in
   world space before the camera transform; flat (per-face) shading of a constant white texture.
   look_at / look: z = normalize(at - eye) (or the given direction), x = normalize(up x z), y = normalize(z x x); v_cam = (v - eye) R^T.
@@ -47,10 +48,15 @@ def look(vertices, eye, direction, up=(0., 1., 0.)):
 
 
 def perspective(v, angle_deg=30.0):
+    """neural_renderer/perspective.py WITH the three lines the reference's README prescribes (README.md:126-134: `x[z<=0] = 0`,
+    `y[z<=0] = 0`, `z[z<=0] = 0` after the division -- "objects behind the camera will also be rendered" otherwise): a vertex behind
+    the camera becomes (0, 0, 0); a face that owns one then interpolates 1 / z = inf and fails the near test"""
     w = np.tan(np.deg2rad(angle_deg))
     out = v.copy()
-    out[:, 0] = v[:, 0] / v[:, 2] / w
-    out[:, 1] = v[:, 1] / v[:, 2] / w
+    with np.errstate(divide="ignore", invalid="ignore"):
+        out[:, 0] = v[:, 0] / v[:, 2] / w
+        out[:, 1] = v[:, 1] / v[:, 2] / w
+    out[v[:, 2] <= 0] = 0.0
     return out
 
 

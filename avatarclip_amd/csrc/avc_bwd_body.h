@@ -31,6 +31,27 @@
 #ifndef AVC_BWD_RR_NT
 #define AVC_BWD_RR_NT 1
 #endif
+// Round 5 (the kernel's self-re-reads, 70 tiles per block).  Timing ablations -- results are garbage --
+//   AVC_ABL_BWD_NOEH    the second-order sweep does not load its h tiles (an opaque constant instead): what ANY scheme that removes the
+//                       first of the two h reads (31 tiles) could gain at most
+//   AVC_ABL_BWD_NORR    the reverse sweep does not re-read the tiles this kernel wrote itself (gbar_h 31, ybar[1:] 8 tiles)
+//   AVC_ABL_BWD_RECOMP  NOEH + the price of recomputing h inside the second-order sweep from the staged W_l fragments, priced LOW: a
+//                       second MFMA chain per tile on the same A fragments (one LDS read feeds two MFMAs) + the 16 softplus per lane
+//                       and tile, but NOT the second input array (64 VGPRs) nor the f16 weight set a real version needs
+// and one real variant (parity-valid):
+//   AVC_BWD_KEEP_GBS    turn-around residency: gbar_hs (the last tiles the second-order sweep produces, the first the reverse sweep
+//                       consumes) stays in registers across the turn instead of being re-read (7 tiles); = 2: h_s as well (14 tiles)
+#ifndef AVC_BWD_KEEP_GBS
+#define AVC_BWD_KEEP_GBS 0
+#endif
+template <typename V>
+__device__ __forceinline__ FragPair<V> abl_const_pair() {
+  FragPair<V> d;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { d.a0[j] = (typename MF<V>::S)0.75f; d.a1[j] = (typename MF<V>::S)1.25f; }
+  asm volatile("" : "+v"(d.a0), "+v"(d.a1));
+  return d;
+}
 
 template <typename P> __device__ __forceinline__ P launder(P p) {
   asm volatile("" : "+s"(p));
@@ -169,6 +190,10 @@ __device__ __forceinline__ void bwd_sweeps(StageT<BWD_G>& sg, const BwdArgs& a, 
     tile_store<false>(tiles, L::G_ONE, fo, zero_frag<b8>());
   }
   // ------------------------------------------------------------------ phase E: second-order sweep (i) (bf16)
+  b8 gbs[N::SK];        // gbar_hs: with AVC_BWD_KEEP_GBS it stays in registers for the first layer of the reverse sweep
+#if AVC_BWD_KEEP_GBS >= 2
+  h8 hs_keep[N::SK];    // ... and so does h_s
+#endif
   {
     b8 gb0[3];
     {
@@ -180,26 +205,37 @@ __device__ __forceinline__ void bwd_sweeps(StageT<BWD_G>& sg, const BwdArgs& a, 
     tile_store<false>(tiles, L::G_GB0, gb0[0], gb0[1]);
     tile_store<false>(tiles, L::G_GB0 + 1, gb0[2], zero_frag<b8>());
     // gbar_a = W gbar_h(in); gbar_h(out) = gbar_a * sigma(h_out)
-#define AVC_SECOND(OUT, PH, PT)                                                                             \
-  AVC_PRE(return tile_load<(AVC_BWD_E_NT != 0), h8>(ftiles, (PH) + t);),                                     \
+#if defined(AVC_ABL_BWD_NOEH) || defined(AVC_ABL_BWD_RECOMP)
+#define AVC_E_LOADH(PH) abl_const_pair<h8>()
+#else
+#define AVC_E_LOADH(PH) tile_load<(AVC_BWD_E_NT != 0), h8>(ftiles, (PH) + t)
+#endif
+#define AVC_SECOND_(OUT, PH, PT, KEEPH)                                                                      \
+  AVC_PRE(return AVC_E_LOADH(PH);),                                                                          \
   AVC_EPID(FragPair<h8>, _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                     \
             OUT[2 * t][j] = (__bf16)(acc[j] * sig_from_h((float)d.a0[j]));                                   \
             OUT[2 * t + 1][j] = (__bf16)(acc[8 + j] * sig_from_h((float)d.a1[j])); }                         \
           pin2(OUT[2 * t], OUT[2 * t + 1]);                                                                  \
+          KEEPH                                                                                              \
           tile_store<true>(tiles, (PT) + t, OUT[2 * t], OUT[2 * t + 1]);)
+#define AVC_SECOND(OUT, PH, PT) AVC_SECOND_(OUT, PH, PT, )
+#if AVC_BWD_KEEP_GBS >= 2
+#define AVC_SECOND_S(OUT, PH, PT) AVC_SECOND_(OUT, PH, PT, hs_keep[2 * t] = d.a0; hs_keep[2 * t + 1] = d.a1;)
+#else
+#define AVC_SECOND_S(OUT, PH, PT) AVC_SECOND_(OUT, PH, PT, )
+#endif
     b8 gb1[N::HK];
     layer_sqd<b8, 3, N::HT>(sg, Wb, o.v[OFF_W0G], nxt<N, OFF_WM0>(sg, Wb, o), gb0, AVC_SECOND(gb1, L::P_H1, L::G_GBH1));
     b8 gbm[N::HK];
-    b8 gbs[N::SK];
     if constexpr (N::NMID == 2) {
       layer_sqd<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wb, o), gb1, AVC_SECOND(gbm, L::P_HM, L::G_GBHM));
       b8 gbm1[N::HK];
       layer_sqd<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wb, o), gbm,
                                   AVC_SECOND(gbm1, L::P_HM + N::HT, L::G_GBHM + N::HT));
-      layer_sqd<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WS], nxt<N, OFF_WLT>(sg, Wb, o), gbm1, AVC_SECOND(gbs, L::P_HS, L::G_GBHS));
+      layer_sqd<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WS], nxt<N, OFF_WLT>(sg, Wb, o), gbm1, AVC_SECOND_S(gbs, L::P_HS, L::G_GBHS));
     } else {
       layer_sqd<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wb, o), gb1, AVC_SECOND(gbm, L::P_HM, L::G_GBHM));
-      layer_sqd<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WS], nxt<N, OFF_WLT>(sg, Wb, o), gbm, AVC_SECOND(gbs, L::P_HS, L::G_GBHS));
+      layer_sqd<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WS], nxt<N, OFF_WLT>(sg, Wb, o), gbm, AVC_SECOND_S(gbs, L::P_HS, L::G_GBHS));
     }
   }
   // ------------------------------------------------------------------ phase F: reverse sweep (ii) (bf16)
@@ -208,17 +244,39 @@ __device__ __forceinline__ void bwd_sweeps(StageT<BWD_G>& sg, const BwdArgs& a, 
     b8 dfeat[N::HK];
 #pragma unroll
     for (int t = 0; t < N::HT; ++t) {
+#ifdef AVC_ABL_BWD_NORR
+      const FragPair<b8> d = abl_const_pair<b8>();
+#else
       const FragPair<b8> d = tile_load<(AVC_BWD_RR_NT != 0), b8>(tiles, L::G_DFEAT + t);
+#endif
       dfeat[2 * t] = d.a0;
       dfeat[2 * t + 1] = d.a1;
     }
+#ifdef AVC_ABL_BWD_NORR
+#define AVC_F_LOADB(PB) abl_const_pair<b8>()
+#else
+#define AVC_F_LOADB(PB) tile_load<(AVC_BWD_RR_NT != 0), b8>(tiles, (PB) + t)
+#endif
 #define AVC_LOAD3(PH, PB, PG)                                                                               \
   AVC_PRE(PF3 d; { const FragPair<h8> a_ = tile_load<true, h8>(ftiles, (PH) + t); d.h0 = a_.a0; d.h1 = a_.a1; } \
-          { const FragPair<b8> a_ = tile_load<(AVC_BWD_RR_NT != 0), b8>(tiles, (PB) + t); d.b0 = a_.a0; d.b1 = a_.a1; } \
+          { const FragPair<b8> a_ = AVC_F_LOADB(PB); d.b0 = a_.a0; d.b1 = a_.a1; } \
           { const FragPair<h8> a_ = tile_load<true, h8>(ftiles, (PG) + t); d.g0 = a_.a0; d.g1 = a_.a1; } return d;)
+  // the same for the first layer of the reverse sweep: gbar_hs (and h_s) straight from the registers of the second-order sweep when kept
+#if AVC_BWD_KEEP_GBS >= 2
+#define AVC_LOAD3_S(PH, PB, PG)                                                                             \
+  AVC_PRE(PF3 d; d.h0 = hs_keep[2 * t]; d.h1 = hs_keep[2 * t + 1]; d.b0 = gbs[2 * t]; d.b1 = gbs[2 * t + 1];  \
+          { const FragPair<h8> a_ = tile_load<true, h8>(ftiles, (PG) + t); d.g0 = a_.a0; d.g1 = a_.a1; } return d;)
+#elif AVC_BWD_KEEP_GBS == 1
+#define AVC_LOAD3_S(PH, PB, PG)                                                                             \
+  AVC_PRE(PF3 d; { const FragPair<h8> a_ = tile_load<true, h8>(ftiles, (PH) + t); d.h0 = a_.a0; d.h1 = a_.a1; } \
+          d.b0 = gbs[2 * t]; d.b1 = gbs[2 * t + 1];                                                          \
+          { const FragPair<h8> a_ = tile_load<true, h8>(ftiles, (PG) + t); d.g0 = a_.a0; d.g1 = a_.a1; } return d;)
+#else
+#define AVC_LOAD3_S(PH, PB, PG) AVC_LOAD3(PH, PB, PG)
+#endif
     // ubar[:SKIP]/sqrt2 = (W_last[1:,:]^T dfeat + W_last[0,:] d_sdf)/sqrt2 ; 1/sqrt2 is folded into both packs
     layer_sq<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WLT], nxt<N, OFF_WST>(sg, Wb, o), dfeat,
-      AVC_LOAD3(L::P_HS, L::G_GBHS, L::P_GAS), AVC_EPID(PF3,
+      AVC_LOAD3_S(L::P_HS, L::G_GBHS, L::P_GAS), AVC_EPID(PF3,
       float wa[16];
       load16(T + o.v[OFF_WL0_ACC], t, h, wa);
       _Pragma("unroll") for (int j = 0; j < 8; ++j) {
@@ -260,5 +318,10 @@ __device__ __forceinline__ void bwd_sweeps(StageT<BWD_G>& sg, const BwdArgs& a, 
 #undef AVC_RELU_BWD
 #undef AVC_SECOND
 #undef AVC_LOAD3
+#undef AVC_LOAD3_S
+#undef AVC_F_LOADB
+#undef AVC_E_LOADH
+#undef AVC_SECOND_
+#undef AVC_SECOND_S
 #undef AVC_REVERSE
 }

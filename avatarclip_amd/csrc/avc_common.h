@@ -180,6 +180,30 @@ __device__ __forceinline__ float softplus2(float t) {
   return relu_raw(t) + __builtin_amdgcn_logf(1.f + e);
 #endif
 }
+// softplus2 of a whole accumulator tile.  AVC_SOFTPLUS_PK=1 (experiment): the "1 + 2^t" adds on register PAIRS
+// (v_pk_add_f32) -- 8 instead of 16 plain adds per tile; MI355X_MICROARCH.md prices a packed-f32 op beside MFMAs at ~13 cycles MORE than
+// the two scalar ops it replaces, which is what profiles/r05_ab_kernels.txt measures.
+#ifndef AVC_SOFTPLUS_PK
+#define AVC_SOFTPLUS_PK 0
+#endif
+typedef float f2v __attribute__((ext_vector_type(2)));
+template <typename A>
+__device__ __forceinline__ void softplus2_tile(const A& acc, float (&a)[16]) {
+#if AVC_SOFTPLUS_PK && AVC_SOFTPLUS_DIRECT && !defined(AVC_ABL_CHEAPACT)
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    f2v e = {__builtin_amdgcn_exp2f(acc[r]), __builtin_amdgcn_exp2f(acc[r + 1])};
+    const f2v one = {1.f, 1.f};
+    e = e + one;
+    asm("" : "+v"(e));   // keep the pair together: the add stays ONE packed instruction
+    a[r] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_logf(e[0]), acc[r], 128.f);
+    a[r + 1] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_logf(e[1]), acc[r + 1], 128.f);
+  }
+#else
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r]);
+#endif
+}
 // The same activation evaluated AFTER the f16 conversion the next layer's operand needs anyway (experiment, AVC_SDF_F16_ACT; VERDICT r3
 // item 6): v_cvt_pk_f16_f32, v_exp_f16, v_pk_add_f16, v_log_f16 and the overflow repair as v_pk_max_f16 / v_pk_min_f16 -- H = min(log2(1 +
 // 2^t), max(t, 16)): 2^t overflows f16 from t = 16 on, the logarithm then returns +inf and max(t, 16) = t is the minimum; below, L <= 16 <=

@@ -220,7 +220,7 @@ __device__ __forceinline__ void layer_s1(ST& st, const V* __restrict__ blob, int
 // DEEP = false: pre(t-1) goes out before the chain of tile t (one chain of head start, one load set live);
 // DEEP = true:  pre(t) goes out before the chain of tile t (two chains + one epilogue of head start, two sets live) --
 //               measured slower for the three-array loads of the reverse sweep (register pressure), see DESIGN.md 5.
-template <bool AVC_PRE_DEEP, bool PAIRED, typename V, int KS, int NT, class ST, typename Pre, typename Epi, typename Hook>
+template <bool AVC_PRE_DEEP, bool PAIRED, bool DUAL, typename V, int KS, int NT, class ST, typename Pre, typename Epi, typename Hook>
 __device__ __forceinline__ void layer_sq_(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&in)[KS],
                                          Pre&& pre, Epi&& epi, Hook&& hook) {
   constexpr int G = ST::template group<KS>();
@@ -275,8 +275,17 @@ __device__ __forceinline__ void layer_sq_(ST& st, const V* __restrict__ blob, in
     __builtin_amdgcn_sched_barrier(0);
     return;
   }
-  facc prev;
+  facc prev, prev2;
   decltype(pre(0)) dprev{}, dcur{};
+  // DUAL (timing ablation AVC_ABL_BWD_RECOMP): every tile runs a second chain on the same A fragments and its epilogue pays 16 softplus
+  auto fold2 = [&](const facc& a, const facc& a2) __attribute__((always_inline)) {
+    facc r = a;
+    if constexpr (DUAL) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) r[q] += 1e-38f * softplus2(a2[q]);
+    }
+    return r;
+  };
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     AVC_SYNC();
@@ -300,9 +309,19 @@ __device__ __forceinline__ void layer_sq_(ST& st, const V* __restrict__ blob, in
           dprev = pre(t - 1);
           __builtin_amdgcn_sched_barrier(0);
         }
-        facc acc = tile_mma<V, KS>(st, j, in);
-        if (t > 0) { epi(t - 1, prev, dprev); interleave_mfma_valu<KS>(); }
+        facc acc, acc2;
+        if constexpr (DUAL) {
+          const V* a = reinterpret_cast<const V*>(st.lds + st.par * ST::BUF_BYTES + j * KS * 1024) + st.lane;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 1.f; }
+          asm volatile("" : "+v"(acc2));
+          acc = mma_chain_lds_dual<V, KS>(a, in, acc, acc2);
+        } else {
+          acc = tile_mma<V, KS>(st, j, in);
+        }
+        if (t > 0) { epi(t - 1, fold2(prev, prev2), dprev); interleave_mfma_valu<KS>(); }
         prev = acc;
+        if constexpr (DUAL) prev2 = acc2;
         if (AVC_PRE_DEEP) dprev = dcur;
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -310,18 +329,22 @@ __device__ __forceinline__ void layer_sq_(ST& st, const V* __restrict__ blob, in
     st.par ^= 1;
   }
   if (!AVC_PRE_DEEP) dprev = pre(NT - 1);
-  epi(NT - 1, prev, dprev);
+  epi(NT - 1, fold2(prev, prev2), dprev);
   __builtin_amdgcn_sched_barrier(0);
 }
 template <typename V, int KS, int NT, class ST, typename Pre, typename Epi, typename Hook = NoHook>
 __device__ __forceinline__ void layer_sq(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&in)[KS],
                                          Pre&& pre, Epi&& epi, Hook&& hook = NoHook{}) {
-  layer_sq_<false, (AVC_PAIR_SQ != 0), V, KS, NT>(st, blob, offw, after, in, pre, epi, hook);
+  layer_sq_<false, (AVC_PAIR_SQ != 0), false, V, KS, NT>(st, blob, offw, after, in, pre, epi, hook);
 }
 template <typename V, int KS, int NT, class ST, typename Pre, typename Epi, typename Hook = NoHook>
 __device__ __forceinline__ void layer_sqd(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&in)[KS],
                                           Pre&& pre, Epi&& epi, Hook&& hook = NoHook{}) {
-  layer_sq_<AVC_DEEP_PF1 != 0, (AVC_PAIR_SQ != 0), V, KS, NT>(st, blob, offw, after, in, pre, epi, hook);
+#ifdef AVC_ABL_BWD_RECOMP
+  layer_sq_<AVC_DEEP_PF1 != 0, false, true, V, KS, NT>(st, blob, offw, after, in, pre, epi, hook);
+#else
+  layer_sq_<AVC_DEEP_PF1 != 0, (AVC_PAIR_SQ != 0), false, V, KS, NT>(st, blob, offw, after, in, pre, epi, hook);
+#endif
 }
 template <typename V, int KA, int KB, int NT, class ST, typename Epi, typename Hook = NoHook, class Bias = NoBias>
 __device__ __forceinline__ void layer2_s(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&ina)[KA],
@@ -513,7 +536,7 @@ __device__ __forceinline__ float sdf_only(ST& sg, const h8* __restrict__ Wf, TP 
       layer_s1<h8, 3, N::HT>(sg, Wf, o.v[OFF_W0], nxt<N, OFF_WM0>(sg, Wf, o), pef, AVC_EPI(
         if constexpr (AVC_SDF_F16_ACT != 0) { softplus_frags_f16(acc, h1[2 * t], h1[2 * t + 1]); } else {
         float a[16];
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r]);
+        softplus2_tile(acc, a);
         acc_to_frags(a, h1[2 * t], h1[2 * t + 1]); }
       ), NoHook{}, TabBias{T + o.v[OFF_B0], h});
     }
@@ -522,20 +545,20 @@ __device__ __forceinline__ float sdf_only(ST& sg, const h8* __restrict__ Wf, TP 
       layer_s1<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wf, o), h1, AVC_EPI(
         if constexpr (AVC_SDF_F16_ACT != 0) { softplus_frags_f16(acc, hm0[2 * t], hm0[2 * t + 1]); } else {
         float a[16];
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r]);
+        softplus2_tile(acc, a);
         acc_to_frags(a, hm0[2 * t], hm0[2 * t + 1]); }
       ), NoHook{}, TabBias{T + o.v[OFF_BM0], h});
       layer_s1<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wf, o), hm0, AVC_EPI(
         if constexpr (AVC_SDF_F16_ACT != 0) { softplus_frags_f16(acc, hlast[2 * t], hlast[2 * t + 1]); } else {
         float a[16];
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r]);
+        softplus2_tile(acc, a);
         acc_to_frags(a, hlast[2 * t], hlast[2 * t + 1]); }
       ), NoHook{}, TabBias{T + o.v[OFF_BM1], h});
     } else {
       layer_s1<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wf, o), h1, AVC_EPI(
         if constexpr (AVC_SDF_F16_ACT != 0) { softplus_frags_f16(acc, hlast[2 * t], hlast[2 * t + 1]); } else {
         float a[16];
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) a[r] = softplus2(acc[r]);
+        softplus2_tile(acc, a);
         acc_to_frags(a, hlast[2 * t], hlast[2 * t + 1]); }
       ), NoHook{}, TabBias{T + o.v[OFF_BM0], h});
     }

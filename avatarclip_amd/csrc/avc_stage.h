@@ -116,6 +116,27 @@ __device__ __forceinline__ facc mma_chain_lds(const V* __restrict__ a_lds /* lan
 }
 
 
+// timing ablation (AVC_ABL_BWD_RECOMP, csrc/avc_bwd_body.h): a second accumulator chain on the SAME A fragments -- one LDS read feeds
+// two MFMAs -- which is what recomputing h_l inside the second-order sweep would add to its MFMA stream at the very least
+template <typename V, int KS>
+__device__ __forceinline__ facc mma_chain_lds_dual(const V* __restrict__ a_lds, const V (&in)[KS], facc acc, facc& acc2) {
+  V a[KS];
+#pragma unroll
+  for (int s = 0; s < KS && s < AVC_LDS_AHEAD; ++s) a[s] = a_lds[s * 64];
+#pragma unroll
+  for (int s = 0; s < KS; s += 4) {
+    if (s + 3 < KS) pin4(a[s], a[s + 1], a[s + 2], a[s + 3]);
+#pragma unroll
+    for (int k = s + AVC_LDS_AHEAD; k < s + AVC_LDS_AHEAD + 4 && k < KS; ++k) a[k] = a_lds[k * 64];
+#pragma unroll
+    for (int k = s; k < s + 4 && k < KS; ++k) {
+      acc = MF<V>::mma(a[k], in[k], acc);
+      acc2 = MF<V>::mma(a[k], in[k], acc2);
+    }
+  }
+  return acc;
+}
+
 // where the accumulator of an output tile starts: zero, or the tile's bias row from the fp32 table in LDS (see tile_mma below)
 struct NoBias { static constexpr bool on = false; };
 struct TabBias { static constexpr bool on = true; lds_tab_t tab; int h; };

@@ -17,7 +17,9 @@ def init_from_env(backend=None):
     # single-rank job then runs the same broadcast / flat-bucket all-reduce path over RCCL as the 8-rank one
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if world > 1:
-        pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        pin_host_threads(local_rank, local_world)
+        check_queue_oversubscription(local_world)
     if (world > 1 or launched) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -31,24 +33,118 @@ def init_from_env(backend=None):
     return rank, world, local_rank
 
 
+def _parse_cpulist(text):
+    """'0-63,128-191' -> [0..63, 128..191] (the kernel's cpulist format)"""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_numa_nodes(sysfs="/sys"):
+    """NUMA node of every amdgpu device in HIP's default enumeration order (PCI bus order of the render-capable amdgpu functions
+    under /sys/bus/pci/drivers/amdgpu; HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES index lists are applied on top).  -1 = unknown.
+    Returns [] where the topology is not readable (containers without /sys, other platforms)."""
+    drv = os.path.join(sysfs, "bus", "pci", "drivers", "amdgpu")
+    try:
+        devs = sorted(d for d in os.listdir(drv) if d.count(":") == 2)
+    except OSError:
+        return []
+    nodes = []
+    for d in devs:
+        try:
+            with open(os.path.join(drv, d, "numa_node")) as f:
+                nodes.append(int(f.read().strip()))
+        except (OSError, ValueError):
+            nodes.append(-1)
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        vis = os.environ.get(var)
+        if vis and all(t.strip().isdigit() for t in vis.split(",")):
+            idx = [int(t) for t in vis.split(",")]
+            if all(i < len(nodes) for i in idx):
+                nodes = [nodes[i] for i in idx]
+            break
+    return nodes
+
+
+def numa_cpus(node, sysfs="/sys"):
+    try:
+        with open(os.path.join(sysfs, "devices", "system", "node", "node%d" % node, "cpulist")) as f:
+            return _parse_cpulist(f.read())
+    except (OSError, ValueError):
+        return []
+
+
+def core_slice(local_rank, local_world, allowed, gpu_nodes=None, node_cpus=None):
+    """The host cores of rank `local_rank`: the cores of the NUMA node its GPU hangs off, divided evenly among the ranks whose GPUs
+    share that node (a launch-heavy host process on the far socket pays a cross-socket hop on every doorbell and every pinned-buffer
+    write); without a readable topology -- or when the node's cores are not in this process's affinity mask -- the r-th of
+    `local_world` equal slices of the allowed cores, by index.  Pure function of its arguments (tests/test_parallel_gloo.py runs it on
+    fake topologies): gpu_nodes[r] = NUMA node of rank r's device or -1, node_cpus[n] = cores of node n."""
+    allowed = sorted(allowed)
+    r = local_rank % max(1, local_world)
+    if gpu_nodes and node_cpus and r < len(gpu_nodes) and gpu_nodes[r] >= 0:
+        node = gpu_nodes[r]
+        cand = [c for c in node_cpus.get(node, []) if c in set(allowed)]
+        peers = [q for q in range(min(local_world, len(gpu_nodes))) if gpu_nodes[q] == node]
+        if cand and r in peers:
+            per = len(cand) // len(peers)
+            if per >= 1:
+                k = peers.index(r)
+                return cand[k * per:(k + 1) * per]
+    per = max(1, len(allowed) // max(1, local_world))
+    return allowed[r * per:(r + 1) * per] or allowed
+
+
 def pin_host_threads(local_rank, local_world):
-    """N launch-heavy host processes on one node (639 launches per step each at 512^2): give every rank its own slice of the cores
-    (intra-op torch threads = the slice, CPU affinity = the slice) instead of N x all-cores thread pools fighting each other.
-    AVC_PIN_THREADS=0 leaves both alone."""
+    """N launch-heavy host processes on one node (~245 launches per step each at 512^2): give every rank its own slice of the cores
+    (intra-op torch threads = the slice, CPU affinity = the slice) instead of N x all-cores thread pools fighting each other -- the
+    slice taken from the NUMA node of the rank's GPU (core_slice).  AVC_PIN_THREADS=0 leaves both alone."""
     if os.environ.get("AVC_PIN_THREADS", "1") == "0" or local_world <= 1:
         return None
     try:
         cores = sorted(os.sched_getaffinity(0))
     except AttributeError:          # not on this platform
         return None
-    per = max(1, len(cores) // local_world)
-    mine = cores[(local_rank % local_world) * per:(local_rank % local_world + 1) * per] or cores
+    nodes = gpu_numa_nodes()
+    mine = core_slice(local_rank, local_world, cores, nodes, {n: numa_cpus(n) for n in set(nodes) if n >= 0})
     try:
         os.sched_setaffinity(0, mine)
     except OSError:
         return None
     torch.set_num_threads(max(1, min(len(mine), 16)))
     return mine
+
+
+def check_queue_oversubscription(local_world, n_devices=None, warn=None):
+    """More ranks than devices on a node (a shared node, or the single-device rig of the tests): every process opens GPU_MAX_HW_QUEUES
+    hardware queues (default 4) on the device it shares; beyond the device's queue slots the scheduler time-slices wavefronts by
+    context save / restore, and under that a launch died with HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION in 2 of 5 runs with 8 processes on
+    one MI355X (never with <= 6, never with GPU_MAX_HW_QUEUES <= 2).  Returns the warning text (and emits it) when
+    the process is in that regime and has not capped its queues; None otherwise.  One process per GPU -- the product's layout -- never is."""
+    if n_devices is None:
+        n_devices = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_devices <= 0 or local_world <= n_devices:
+        return None
+    per_dev = -(-local_world // n_devices)
+    try:
+        q = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        q = 4
+    if per_dev * q <= 16:
+        return None
+    msg = ("avatarclip_amd: %d ranks share %d device(s) (%d processes x %d hardware queues per device): wavefront preemption under "
+           "queue oversubscription has crashed launches on MI355X -- set GPU_MAX_HW_QUEUES=2 (or run one rank per GPU)"
+           % (local_world, n_devices, per_dev, q))
+    if warn is None:
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=2)
+    else:
+        warn(msg)
+    return msg
 
 
 def is_on():

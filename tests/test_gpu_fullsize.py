@@ -121,18 +121,21 @@ def test_fullsize_one_launch_render_matches_oracle_on_256_rays():
         assert e.max() < tol, key
 
 
-@gpu
-def test_fullsize_dense_gradient_of_256_rays_matches_the_oracles_autograd(monkeypatch):
-    """The backward of the 512 x 512 x 64-spp training launch against the oracle (main.py:537 through renderer.py:195-300 and
-    fields.py:72-107,154-185): the loss is supported on the same 256 rays as the forward test (first / last ray, the rays at every
-    4-GiB boundary of the F panel region, random ones) and has zero cotangents everywhere else, so the dense gradient that comes out
-    of the two-slab, 110-GiB backward pass (avc_render_points_bwd + avc_weight_grad_all over 16.8 M points, panel offsets far beyond
-    2^32) must equal the autograd gradient of the oracle rendering just those 256 rays.  SURVEY 8d gate: 1e-2 per tensor (1.5e-2 for
-    the colour tensors, see below; 2e-2 for tensors below 1e-4 of the whole gradient's norm).  The loss takes colours, the CLIP colours, the weight sums and the normals
-    (sum_i w_i n_i, main.py:428) -- not the eikonal term, whose normaliser runs over all rays of the view."""
-    dev = torch.device("cuda")
+def _pick_rays(eng, R, n, spp=64):
+    """_pick_256_rays' set (boundaries first) topped up with random rays to n"""
+    pick = set(_pick_256_rays(eng, R, spp).tolist())
+    rs = np.random.RandomState(17)
+    while len(pick) < n:
+        pick.add(int(rs.randint(0, R)))
+    return torch.tensor(sorted(pick), dtype=torch.long)
+
+
+def _dense_gradient_errors(dev, nsel, two_slabs, monkeypatch):
+    """Dense gradient of ONE 512 x 512 x 64-spp training launch for a loss supported on `nsel` rays (zero cotangents elsewhere) against
+    the oracle's autograd on those rays.  Returns (loss, oracle loss, [(name, rel, cos, tiny)])."""
     from avatarclip_amd.engine import Engine
-    monkeypatch.setattr(Engine, "SLAB_BLOCKS", 256 * 1024)      # two slabs (the default is one slab for this ray set): the boundary is part of the test
+    if two_slabs:
+        monkeypatch.setattr(Engine, "SLAB_BLOCKS", 256 * 1024)      # two slabs (the default is one slab for this ray set): the boundary is part of the test
     sdf, col, var, ren = _full_renderer(dev)
     with torch.no_grad():   # off the degenerate initialisation (the PE columns of layer 0 are zero there), as oracle/gen_golden.py does
         gp = torch.Generator().manual_seed(11)
@@ -146,11 +149,11 @@ def test_fullsize_dense_gradient_of_256_rays_matches_the_oracles_autograd(monkey
     with torch.no_grad():
         z = ren.sample_z(pk, ro, rd, near, far, 1.0, jitter=torch.rand(R, 1, device=dev, generator=torch.Generator(device=dev).manual_seed(9)))
     bg = torch.tensor([[0.1, 0.6, 0.3]], device=dev)
-    idx = _pick_256_rays(eng, R)
+    idx = _pick_256_rays(eng, R) if nsel == 256 else _pick_rays(eng, R, nsel)
     di = idx.to(dev)
     gc = torch.Generator().manual_seed(4)
-    c1, c2, cw = torch.randn(256, 3, generator=gc), torch.randn(256, 3, generator=gc), torch.randn(256, 1, generator=gc)
-    cn = torch.randn(256, 3, generator=gc) * 0.3
+    c1, c2, cw = torch.randn(nsel, 3, generator=gc), torch.randn(nsel, 3, generator=gc), torch.randn(nsel, 1, generator=gc)
+    cn = torch.randn(nsel, 3, generator=gc) * 0.3
 
     def loss_of(out, sel, t):
         nsum = (out["gradients"][sel] * out["weights"][sel][..., None]).sum(1)
@@ -158,7 +161,9 @@ def test_fullsize_dense_gradient_of_256_rays_matches_the_oracles_autograd(monkey
                 + (out["weight_sum"][sel] * t(cw)).sum() + (nsum * t(cn)).sum())
 
     out = ren.render(ro, rd, near, far, background_rgb=bg, cos_anneal_ratio=0.7, z_vals=z)
-    assert eng.rays_per_chunk(R, 64) >= R and eng.plan(R, 64)[1] < R, "one forward launch, more than one backward slab"
+    assert eng.rays_per_chunk(R, 64) >= R, "one forward launch"
+    if two_slabs:
+        assert eng.plan(R, 64)[1] < R, "more than one backward slab"
     loss = loss_of(out, di, lambda v: v.to(dev))
     loss.backward()
     torch.cuda.synchronize()
@@ -169,13 +174,11 @@ def test_fullsize_dense_gradient_of_256_rays_matches_the_oracles_autograd(monkey
                    cos_anneal_ratio=0.7, z_vals=z[di].cpu())
     loss_ref = loss_of(ref, slice(None), lambda v: v)
     loss_ref.backward()
-    print("loss", loss.item(), "oracle", loss_ref.item())
-    assert abs(loss.item() - loss_ref.item()) < 2e-3 * max(1.0, abs(loss_ref.item()))
     pairs = [("sdf." + k_, p.grad, sd_s[k_].grad) for k_, p in sdf.named_parameters()]
     pairs += [("col." + k_, p.grad, sd_c[k_].grad) for k_, p in col.named_parameters()]
     pairs += [("var.variance", var.variance.grad, variance.grad)]
     gnorm = float(np.sqrt(sum(float(r.double().pow(2).sum()) for _, _, r in pairs if r is not None)))
-    bad = []
+    rows = []
     for name, g, r in pairs:
         if r is None or r.abs().max() < 1e-9:
             continue
@@ -183,14 +186,57 @@ def test_fullsize_dense_gradient_of_256_rays_matches_the_oracles_autograd(monkey
         rel = ((g.double() - r.double()).norm() / r.double().norm()).item()
         cos = torch.nn.functional.cosine_similarity(g.reshape(1, -1).double(), r.reshape(1, -1).double()).item()
         tiny = r.double().norm().item() < 1e-4 * gnorm
-        print("  %-22s rel %.3e cos %.6f |ref| %.3e%s" % (name, rel, cos, r.norm().item(), "  (tiny)" if tiny else ""))
+        print("  %5d rays  %-22s rel %.3e cos %.6f |ref| %.3e%s" % (nsel, name, rel, cos, r.norm().item(), "  (tiny)" if tiny else ""))
+        rows.append((name, rel, cos, tiny))
+    return loss.item(), loss_ref.item(), rows
+
+
+@gpu
+def test_fullsize_dense_gradient_of_256_rays_matches_the_oracles_autograd(monkeypatch):
+    """The backward of the 512 x 512 x 64-spp training launch against the oracle (main.py:537 through renderer.py:195-300 and
+    fields.py:72-107,154-185): the loss is supported on the same 256 rays as the forward test (first / last ray, the rays at every
+    4-GiB boundary of the F panel region, random ones) and has zero cotangents everywhere else, so the dense gradient that comes out
+    of the two-slab, 110-GiB backward pass (avc_render_points_bwd + avc_weight_grad_all over 16.8 M points, panel offsets far beyond
+    2^32) must equal the autograd gradient of the oracle rendering just those 256 rays.  SURVEY 8d gate: 1e-2 per tensor; at these
+    16 K points the colour tensors get 1.5e-2 -- their error is sampling noise that falls with the number of points, which
+    test_colour_gradient_error_falls_with_the_number_of_points measures and then holds to 1e-2 at 262 K points.  The loss takes colours,
+    the CLIP colours, the weight sums and the normals (sum_i w_i n_i, main.py:428) -- not the eikonal term, whose normaliser runs over
+    all rays of the view."""
+    dev = torch.device("cuda")
+    loss, loss_ref, rows = _dense_gradient_errors(dev, 256, True, monkeypatch)
+    print("loss", loss, "oracle", loss_ref)
+    assert abs(loss - loss_ref) < 2e-3 * max(1.0, abs(loss_ref))
+    bad = []
+    for name, rel, cos, tiny in rows:
         # SDF tensors: SURVEY's 1e-2 (measured 0.01-0.31 %, the sdf bias -- a heavily cancelling sum -- 0.03 % out of the hi + lo d_sdf
-        # tile).  Colour tensors: 1.5e-2 -- layer 0 sits at 1.0-1.2 % here as in the golden-gradient test: ReLU units whose f16-operand
-        # pre-activation has the other sign than the fp32 one (|pre| below ~5e-4 of its scale) flip their whole contribution; that
-        # is sampling noise of the 16 K points, not a bias (two runs that differ by one fp32 ulp in the weights: 1.10 / 1.27 %)
+        # tile).  Colour tensors at 16 K points: 1.5e-2 (layer 0 sits at 1.0-1.2 %: ReLU units whose f16-operand pre-activation has the
+        # other sign than the fp32 one flip their whole contribution -- noise, see the test below)
         gate = 2e-2 if tiny else (1.5e-2 if name.startswith("col.") else 1e-2)
         if not (rel < gate and cos > 0.9995):
             bad.append((name, rel, cos))
+    assert not bad, bad
+
+
+@gpu
+def test_colour_gradient_error_falls_with_the_number_of_points(monkeypatch):
+    """is the 1.0-1.2 % of the colour tensors at 16 K points sampling noise (ReLU sign flips of f16-operand
+    pre-activations, rounding of cancelling sums) or a bias?  Noise falls like 1 / sqrt(points), a bias does not.  The same launch, the
+    same weights, the same kind of loss on 256 rays (16 K points) and on 4 096 rays (262 K points): every colour tensor's relative
+    error must fall by at least 2 x (4 x for pure noise), and at 262 K points EVERY tensor -- colour tensors included, no carve-out --
+    must meet SURVEY 8d's 1e-2 (fields.py:154-185 under main.py:537)."""
+    dev = torch.device("cuda")
+    _, _, small = _dense_gradient_errors(dev, 256, False, monkeypatch)
+    loss, loss_ref, large = _dense_gradient_errors(dev, 4096, False, monkeypatch)
+    assert abs(loss - loss_ref) < 2e-3 * max(1.0, abs(loss_ref))
+    e256 = {n: r for n, r, _, _ in small}
+    bad = []
+    for name, rel, cos, tiny in large:
+        ratio = e256[name] / max(rel, 1e-12)
+        print("  %-22s 256 rays %.3e -> 4096 rays %.3e  (x %.2f)" % (name, e256[name], rel, ratio))
+        if not (rel < 1e-2 and cos > 0.9995):
+            bad.append((name, "gate", rel, cos))
+        if name.startswith("col.") and e256[name] > 3e-3 and ratio < 2.0:
+            bad.append((name, "does not fall", e256[name], rel))
     assert not bad, bad
 
 

@@ -53,3 +53,68 @@ def test_flat_bucket_allreduce_world2():
         assert torch.allclose(a["reduced"][i], mean, atol=1e-7) and torch.allclose(b["reduced"][i], mean, atol=1e-7)
         assert torch.equal(a["params"][i], b["params"][i])
     assert a["mx"] == 1.0 and b["mx"] == 1.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# host-core slices of the ranks of one node (parallel.core_slice / gpu_numa_nodes / numa_cpus) on FAKE topologies: the product reads
+# /sys, the rule itself is a pure function
+def _fake_sysfs(tmp_path, gpu_nodes, node_cpulists):
+    drv = tmp_path / "bus" / "pci" / "drivers" / "amdgpu"
+    for i, node in enumerate(gpu_nodes):
+        d = drv / ("0000:%02x:00.0" % (0x10 + 0x10 * i))
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text("%d\n" % node)
+    (drv / "module").mkdir()          # non-device entries of the driver directory are ignored
+    for n, text in node_cpulists.items():
+        nd = tmp_path / "devices" / "system" / "node" / ("node%d" % n)
+        nd.mkdir(parents=True)
+        (nd / "cpulist").write_text(text + "\n")
+    return str(tmp_path)
+
+
+def test_core_slices_follow_the_numa_node_of_each_rank_s_gpu(tmp_path, monkeypatch):
+    from avatarclip_amd import parallel
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    # an 8-GPU, two-socket node: GPUs 0-3 on node 0, 4-7 on node 1; node 0 = cores 0-63 + SMT siblings 128-191, node 1 = the rest
+    root = _fake_sysfs(tmp_path, [0, 0, 0, 0, 1, 1, 1, 1], {0: "0-63,128-191", 1: "64-127,192-255"})
+    nodes = parallel.gpu_numa_nodes(root)
+    assert nodes == [0, 0, 0, 0, 1, 1, 1, 1]
+    cpus = {n: parallel.numa_cpus(n, root) for n in (0, 1)}
+    assert len(cpus[0]) == 128 and cpus[0][:2] == [0, 1] and cpus[0][64] == 128
+    allowed = list(range(256))
+    slices = [parallel.core_slice(r, 8, allowed, nodes, cpus) for r in range(8)]
+    assert all(len(s) == 32 for s in slices)
+    assert len(set(c for s in slices for c in s)) == 256, "the slices partition the node's cores"
+    for r, s in enumerate(slices):
+        assert set(s) <= set(cpus[0 if r < 4 else 1]), "rank %d left the socket of its GPU" % r
+    # the index rule would have put rank 2 on cores 64-95 (socket 1) although its GPU hangs off socket 0
+    assert parallel.core_slice(2, 8, allowed)[0] == 64 and slices[2][0] in cpus[0]
+    # interleaved enumeration (GPU i on node i % 2), 4 ranks
+    nodes2 = [0, 1, 0, 1]
+    s2 = [parallel.core_slice(r, 4, allowed, nodes2, cpus) for r in range(4)]
+    assert set(s2[0]) | set(s2[2]) == set(cpus[0]) and set(s2[1]) | set(s2[3]) == set(cpus[1])
+    # a restricted affinity mask (cgroup): only cores the process may use are handed out
+    s3 = parallel.core_slice(5, 8, list(range(64, 96)), nodes, cpus)
+    assert set(s3) <= set(range(64, 96)) and len(s3) == 8
+    # unknown topology (-1), missing /sys, or a node none of whose cores is allowed: the index slice
+    assert parallel.core_slice(3, 8, allowed, [-1] * 8, cpus) == list(range(96, 128))
+    assert parallel.gpu_numa_nodes(str(tmp_path / "nowhere")) == []
+    assert parallel.core_slice(1, 2, list(range(8)), [], {}) == [4, 5, 6, 7]
+    assert parallel.core_slice(0, 8, list(range(200, 208)), nodes, cpus) == [200]
+    # HIP_VISIBLE_DEVICES re-indexes the devices a process sees
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "4,5")
+    assert parallel.gpu_numa_nodes(root) == [1, 1]
+
+
+def test_queue_oversubscription_is_reported_only_when_ranks_share_a_device(monkeypatch):
+    from avatarclip_amd import parallel
+    said = []
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    assert parallel.check_queue_oversubscription(8, 8, said.append) is None          # one process per GPU: the product's layout
+    assert parallel.check_queue_oversubscription(4, 1, said.append) is None          # 4 x 4 queues fit
+    msg = parallel.check_queue_oversubscription(8, 1, said.append)                  # the round-4 rig: 8 x 4 queues on one device
+    assert msg and "GPU_MAX_HW_QUEUES=2" in msg and said == [msg]
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "2")
+    assert parallel.check_queue_oversubscription(8, 1, said.append) is None
+    assert parallel.check_queue_oversubscription(8, 0, said.append) is None          # no device visible (CPU tests)

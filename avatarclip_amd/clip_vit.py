@@ -261,6 +261,7 @@ class ClipVisionB32:
         self._packed = {}
         self._graphed = {}
         self._graph_busy = {}         # batch size -> a replayed forward is waiting for its backward
+        self._warned_busy = False
         self._graph_ws = []           # packing workspaces the captured launches point at
 
     def eval(self):
@@ -354,6 +355,12 @@ class ClipVisionB32:
             # overwrite them (and its embedding, which aliases the graph's static output).  The reference does exactly that when
             # add_no_texture is set (main.py:512 then :524, one image each); Runner merges the two into one B = 2 pass, other
             # callers get the eager launches for the overlapping call.  The instance is free again once its backward has run.
+            if g is not False and self._graph_busy.get(B, False) and not self._warned_busy:
+                self._warned_busy = True
+                import warnings
+                warnings.warn("ClipVisionB32.encode_image: the captured graphs for batch %d are still waiting for the backward of an "
+                              "earlier call; this call runs as ~500 eager launches (Runner releases the graphs at the start of every "
+                              "iteration; other callers: release_graphs())" % B, RuntimeWarning, stacklevel=2)
             if g is not False and not self._graph_busy.get(B, False):
                 self._graph_busy[B] = True
                 out = g(image.float())
@@ -364,6 +371,14 @@ class ClipVisionB32:
                 out.register_hook(_release)
                 return out.clone()       # (its own storage: the static output buffer is rewritten by the next replay)
         return self._encode_image_eager(image)
+
+    def release_graphs(self):
+        """Declare every graph-replayed forward of earlier calls finished.  The busy flag of a captured instance is cleared by a hook
+        in its backward; a grad-enabled call that never reaches backward (an exception between forward and loss.backward(), a skipped
+        non-finite loss, a probe call) would otherwise leave it set for good and every later call would silently take the eager path.
+        Callers with a step structure call this where no earlier graph can still be wanted -- Runner.train_clip_iteration at its top."""
+        for B in self._graph_busy:
+            self._graph_busy[B] = False
 
     def _encode_image_eager(self, image: torch.Tensor) -> torch.Tensor:
         B = image.shape[0]

@@ -42,7 +42,7 @@
 //   AVC_BWD_KEEP_GBS    turn-around residency: gbar_hs (the last tiles the second-order sweep produces, the first the reverse sweep
 //                       consumes) stays in registers across the turn instead of being re-read (7 tiles); = 2: h_s as well (14 tiles)
 #ifndef AVC_BWD_KEEP_GBS
-#define AVC_BWD_KEEP_GBS 0
+#define AVC_BWD_KEEP_GBS 1
 #endif
 template <typename V>
 __device__ __forceinline__ FragPair<V> abl_const_pair() {
@@ -86,15 +86,49 @@ struct BwdArgs {
   const unsigned short* masks;
 };
 
+// The inputs the FIRST MFMA chain and the first epilogues of a block wait for: delta_o (from d_rgb and the forward's colours) and the
+// ReLU masks.  AVC_BWD_PIPE_IN=1: the persistent kernel requests them for its NEXT block under the last layer of the current one
+// (loop-carried, 20 VGPRs) instead of at the top of the block, where all eight wavefronts sit out one exposed HBM round trip.
+#ifndef AVC_BWD_PIPE_IN
+#define AVC_BWD_PIPE_IN 1   // (profiles/r05_ab_kernels.txt: 9.81 -> 9.48 ms per 4 Mi points)
+#endif
+template <class N> struct BlkIn { b8 dof; unsigned m1[N::HT], m2[N::HT]; };
+template <class N>
+__device__ __forceinline__ void load_blk_in(const BwdArgs& a, long blk, long nblk, int lane, BlkIn<N>& bi) {
+  typedef PanelLayout<N> L;
+  const int h = lane >> 5, p = lane & 31;
+  long i = blk * 32 + p;
+  const float vmask = i < a.npts ? 1.f : 0.f;
+  if (i >= a.npts) i = a.npts - 1;
+  // delta_o = d_rgb * rgb (1 - rgb) with the colours of the forward pass; half 0: outputs 0..3, half 1: outputs 4,5
+  bi.dof = zero_frag<b8>();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ch = h ? 4 + r : r;
+    const float c = (ch < 6) ? a.rgb_fwd[6 * i + (ch < 6 ? ch : 0)] : 0.f;
+    const float dr = (ch < 6) ? a.d_rgb[6 * i + (ch < 6 ? ch : 0)] * vmask : 0.f;
+    bi.dof[r] = (__bf16)(dr * c * (1.f - c));
+  }
+  // ReLU masks of r1 / r2 (16 bits per tile and lane, written by the forward kernel: accumulator register r at bit relu_mask_bit(r))
+  const AVC_GLOBAL unsigned short* mk = as_global(a.masks) + (blk < nblk ? blk : nblk) * (long)L::MASK_U16 + lane;
+#pragma unroll
+  for (int t = 0; t < N::HT; ++t) {
+    bi.m1[t] = mk[t * 64];
+    bi.m2[t] = (N::NCMID == 1) ? mk[(N::HT + t) * 64] : 0u;
+  }
+}
+
 struct NoRing {
   static constexpr bool on = false;
   template <class N> __device__ __forceinline__ void handoff(int, const b8 (&)[N::HK], long, int, int) const {}
 };
 
 // one workgroup iteration: blocks blk0 .. blk0 + BWD_WPB - 1 (wave wv owns block blk0 + wv)
-template <class N, class R>
+// PIPE: `bi` holds this block's inputs on entry and the inputs of block blk0_next + wv on return (plain backward kernel only: the
+// role-specialised kernel claims its blocks dynamically and does not know the next one)
+template <class N, bool PIPE = false, class R>
 __device__ __forceinline__ void bwd_sweeps(StageT<BWD_G>& sg, const BwdArgs& a, lds_tab_t Tl, long blk0, long nblk, int lane0,
-                                           int wv, R& ring) {
+                                           int wv, R& ring, BlkIn<N>* bip = nullptr, long blk0_next = 0) {
   typedef PanelLayout<N> L;
   constexpr AvcOffsets o = Off<N>::value;
   const PointSrc& ps = a.ps;
@@ -113,7 +147,6 @@ __device__ __forceinline__ void bwd_sweeps(StageT<BWD_G>& sg, const BwdArgs& a, 
   const long bsel = blk < nblk ? blk : nblk;
   const PanelPtr ftiles = panel_ptr(const_cast<char*>(a.fpanels) + bsel * (long)L::P_TILES * 2048, lane);   // forward-type operands: read only
   const PanelPtr tiles = panel_ptr(a.gpanels + bsel * (long)L::G_TILES * 2048, lane);                       // gradient-type operands of this slab
-  const AVC_GLOBAL unsigned short* mk = as_global(a.masks) + (blk < nblk ? blk : nblk) * (long)L::MASK_U16 + lane;
   long i = blk * 32 + p;
   const bool valid = i < npts;
   if (!valid) i = npts - 1;
@@ -124,23 +157,15 @@ __device__ __forceinline__ void bwd_sweeps(StageT<BWD_G>& sg, const BwdArgs& a, 
   // delta_o = d_rgb * rgb (1 - rgb) with the colours of the forward pass; half 0: outputs 0..3, half 1: outputs 4,5
   float nbar[3];
   {
+    BlkIn<N> bi_local;
+    if constexpr (!PIPE) load_blk_in<N>(a, blk, nblk, lane, bi_local);
+    BlkIn<N>& bi = PIPE ? *bip : bi_local;
     b8 dof[1];
-    dof[0] = zero_frag<b8>();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ch = h ? 4 + r : r;
-      const float c = (ch < 6) ? a.rgb_fwd[6 * i + (ch < 6 ? ch : 0)] : 0.f;
-      const float dr = (ch < 6) ? a.d_rgb[6 * i + (ch < 6 ? ch : 0)] * vmask : 0.f;
-      dof[0][r] = (__bf16)(dr * c * (1.f - c));
-    }
+    dof[0] = bi.dof;
     tile_store<false>(tiles, L::G_DO, dof[0], zero_frag<b8>());
-    // ReLU masks of r1 / r2 (16 bits per tile and lane, written by the forward kernel: accumulator register r at bit relu_mask_bit(r))
     unsigned m1[N::HT], m2[N::HT];
 #pragma unroll
-    for (int t = 0; t < N::HT; ++t) {
-      m1[t] = mk[t * 64];
-      m2[t] = (N::NCMID == 1) ? mk[(N::HT + t) * 64] : 0u;
-    }
+    for (int t = 0; t < N::HT; ++t) { m1[t] = bi.m1[t]; m2[t] = bi.m2[t]; }
 #define AVC_RELU_BWD(OUT, MSK, PT)                                                                         \
   AVC_EPI(const unsigned bits = MSK[t];                                                                      \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                    \
@@ -191,6 +216,19 @@ __device__ __forceinline__ void bwd_sweeps(StageT<BWD_G>& sg, const BwdArgs& a, 
   }
   // ------------------------------------------------------------------ phase E: second-order sweep (i) (bf16)
   b8 gbs[N::SK];        // gbar_hs: with AVC_BWD_KEEP_GBS it stays in registers for the first layer of the reverse sweep
+  b8 dfeat[N::HK];      // ybar[1:]: the input of the reverse sweep (written by phase D, read back here)
+  auto load_dfeat = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < N::HT; ++t) {
+#ifdef AVC_ABL_BWD_NORR
+      const FragPair<b8> d = abl_const_pair<b8>();
+#else
+      const FragPair<b8> d = tile_load<(AVC_BWD_RR_NT != 0), b8>(tiles, L::G_DFEAT + t);
+#endif
+      dfeat[2 * t] = d.a0;
+      dfeat[2 * t + 1] = d.a1;
+    }
+  };
 #if AVC_BWD_KEEP_GBS >= 2
   h8 hs_keep[N::SK];    // ... and so does h_s
 #endif
@@ -241,17 +279,7 @@ __device__ __forceinline__ void bwd_sweeps(StageT<BWD_G>& sg, const BwdArgs& a, 
   // ------------------------------------------------------------------ phase F: reverse sweep (ii) (bf16)
   {
     b8 as_[N::SK];
-    b8 dfeat[N::HK];
-#pragma unroll
-    for (int t = 0; t < N::HT; ++t) {
-#ifdef AVC_ABL_BWD_NORR
-      const FragPair<b8> d = abl_const_pair<b8>();
-#else
-      const FragPair<b8> d = tile_load<(AVC_BWD_RR_NT != 0), b8>(tiles, L::G_DFEAT + t);
-#endif
-      dfeat[2 * t] = d.a0;
-      dfeat[2 * t + 1] = d.a1;
-    }
+    load_dfeat();
 #ifdef AVC_ABL_BWD_NORR
 #define AVC_F_LOADB(PB) abl_const_pair<b8>()
 #else
@@ -300,6 +328,8 @@ __device__ __forceinline__ void bwd_sweeps(StageT<BWD_G>& sg, const BwdArgs& a, 
     b8 am[N::HK];
     b8 am0[N::HK];
     const Next first = nxt<N, OFF_CHT>(sg, a.Wb0, o);   // prefetch the first tile of the next block iteration
+    // ... and, in the persistent kernel, the next block's delta_o and masks (issued after the first group barrier of the last layer)
+#define AVC_F_LASTHOOK AVC_HOOK(if constexpr (PIPE) load_blk_in<N>(a, blk0_next + wv, nblk, lane, *bip);)
     if constexpr (N::NMID == 2) {
       layer_sq<b8, N::SK, N::HT>(sg, Wb, o.v[OFF_WST], nxt<N, OFF_WM1T>(sg, Wb, o), as_,
                                  AVC_REVERSE(am, L::P_HM + N::HT, L::G_GBHM + N::HT, L::P_GAM + N::HT, L::G_ABM + N::HT, R::on));
@@ -307,12 +337,12 @@ __device__ __forceinline__ void bwd_sweeps(StageT<BWD_G>& sg, const BwdArgs& a, 
       layer_sq<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM1T], nxt<N, OFF_WM0T>(sg, Wb, o), am,
                                  AVC_REVERSE(am0, L::P_HM, L::G_GBHM, L::P_GAM, L::G_ABM, R::on));
       if constexpr (R::on) ring.template handoff<N>(0, am0, blk0, lane, wv);
-      layer_sq<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0T], first, am0, AVC_REVERSE(am, L::P_H1, L::G_GBH1, L::P_GA1, L::G_AB1, false));
+      layer_sq<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0T], first, am0, AVC_REVERSE(am, L::P_H1, L::G_GBH1, L::P_GA1, L::G_AB1, false), AVC_F_LASTHOOK);
     } else {
       layer_sq<b8, N::SK, N::HT>(sg, Wb, o.v[OFF_WST], nxt<N, OFF_WM0T>(sg, Wb, o), as_,
                                  AVC_REVERSE(am, L::P_HM, L::G_GBHM, L::P_GAM, L::G_ABM, R::on));
       if constexpr (R::on) ring.template handoff<N>(0, am, blk0, lane, wv);
-      layer_sq<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0T], first, am, AVC_REVERSE(am0, L::P_H1, L::G_GBH1, L::P_GA1, L::G_AB1, false));
+      layer_sq<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0T], first, am, AVC_REVERSE(am0, L::P_H1, L::G_GBH1, L::P_GA1, L::G_AB1, false), AVC_F_LASTHOOK);
     }
   }
 #undef AVC_RELU_BWD
@@ -323,5 +353,6 @@ __device__ __forceinline__ void bwd_sweeps(StageT<BWD_G>& sg, const BwdArgs& a, 
 #undef AVC_E_LOADH
 #undef AVC_SECOND_
 #undef AVC_SECOND_S
+#undef AVC_F_LASTHOOK
 #undef AVC_REVERSE
 }

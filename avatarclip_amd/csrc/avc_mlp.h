@@ -135,10 +135,21 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // a hook that spreads its stores over the layer's weight groups: called after EVERY group barrier with (g, number of groups) and
 // stores the g-th share of its tiles (tiles_store_part) -- bursts of 4 instead of 8 tile stores per barrier interval
 #define AVC_HOOKG(...) [&](int grp_, int ngrp_) __attribute__((always_inline)) { __VA_ARGS__ }
+// AVC_STORE_PER_TILE=1 (round 5): a spreading hook is called once per output-TILE step with (t, NT) instead of once per weight group
+// with (g, NG): its tile stores go out one tile (2 KiB per wavefront, 16 KiB per workgroup) at a time, each under ~500 cycles of
+// MFMA work, instead of in bursts of 4 tiles behind a barrier (64 KiB per workgroup against a store path of 64 B/clk: the waves then sit
+// on VMEM back-pressure).  One-shot hooks (AVC_HOOK) still run once, after the first barrier.
+#ifndef AVC_STORE_PER_TILE
+#define AVC_STORE_PER_TILE 1   // (profiles/r05_ab_kernels.txt: training forward 7.51 -> 7.45 ms, plain forward 5.88 -> 5.82 ms per 4 Mi points)
+#endif
 template <typename Hook>
 __device__ __forceinline__ void hook_call(Hook&& hook, int g, int ng) {
-  if constexpr (std::is_invocable_v<Hook, int, int>) hook(g, ng);
+  if constexpr (std::is_invocable_v<Hook, int, int>) { if (!AVC_STORE_PER_TILE) hook(g, ng); }
   else if (g == 0) hook();
+}
+template <typename Hook>
+__device__ __forceinline__ void hook_tile(Hook&& hook, int t, int nt) {
+  if constexpr (std::is_invocable_v<Hook, int, int>) { if (AVC_STORE_PER_TILE) hook(t, nt); }
 }
 
 #ifndef AVC_PAIR
@@ -178,6 +189,8 @@ __device__ __forceinline__ void layer_sp(ST& st, const V* __restrict__ blob, int
       const int t = g * G + j;
       if (t < NT) {
         const bool two = PAIRED && (j + 1 < G) && (t + 1 < NT);
+        hook_tile(hook, t, NT);
+        if (two) hook_tile(hook, t + 1, NT);
         facc a0, a1;
         if (two) tile_mma_pair<V, KS>(st, j, in, a0, a1, bias, t);
         else a0 = tile_mma<V, KS>(st, j, in, bias, t);
@@ -247,6 +260,8 @@ __device__ __forceinline__ void layer_sq_(ST& st, const V* __restrict__ blob, in
         const int t = g * G + j;
         if (t < NT) {
           const bool two = (j + 1 < G) && (t + 1 < NT);
+          hook_tile(hook, t, NT);
+          if (two) hook_tile(hook, t + 1, NT);
           if (np > 0) {
             d0 = pre(tp);
             if (np > 1) d1 = pre(tp + 1);
@@ -302,6 +317,7 @@ __device__ __forceinline__ void layer_sq_(ST& st, const V* __restrict__ blob, in
     for (int j = 0; j < G; ++j) {
       const int t = g * G + j;
       if (t < NT) {
+        hook_tile(hook, t, NT);
         if (AVC_PRE_DEEP) {
           dcur = pre(t);
           __builtin_amdgcn_sched_barrier(0);   // the loads go out before the chain
@@ -373,6 +389,8 @@ __device__ __forceinline__ void layer2_s(ST& st, const V* __restrict__ blob, int
       const int t = g * G + j;
       if (t < NT) {
         const bool two = PAIRED && (j + 1 < G) && (t + 1 < NT);
+        hook_tile(hook, t, NT);
+        if (two) hook_tile(hook, t + 1, NT);
         facc a0, a1;
         if (two) tile_mma2_pair<V, KA, KB>(st, j, ina, inb, a0, a1, bias, t);
         else a0 = tile_mma2<V, KA, KB>(st, j, ina, inb, bias, t);

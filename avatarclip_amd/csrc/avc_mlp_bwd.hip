@@ -32,8 +32,15 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(BwdArgs a) {
   __syncthreads();
   NoRing ring;
   // every wavefront of a workgroup runs the same number of iterations (workgroup-uniform loop bound)
+#if AVC_BWD_PIPE_IN
+  BlkIn<N> bi;     // the block's first inputs, requested one block ahead (csrc/avc_bwd_body.h)
+  load_blk_in<N>(a, (long)blockIdx.x * BWD_WPB + wv, nblk, lane0, bi);
+  for (long blk0 = (long)blockIdx.x * BWD_WPB; blk0 < nblk; blk0 += (long)gridDim.x * BWD_WPB)
+    bwd_sweeps<N, true>(sg, a, Tl, blk0, nblk, lane0, wv, ring, &bi, blk0 + (long)gridDim.x * BWD_WPB);
+#else
   for (long blk0 = (long)blockIdx.x * BWD_WPB; blk0 < nblk; blk0 += (long)gridDim.x * BWD_WPB)
     bwd_sweeps<N>(sg, a, Tl, blk0, nblk, lane0, wv, ring);
+#endif
 }
 
 extern "C" int avc_render_points_bwd(int net, const float* pts, const float* rays_o, const float* rays_d, const float* z,

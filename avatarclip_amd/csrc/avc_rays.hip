@@ -285,14 +285,15 @@ __global__ __launch_bounds__(256) void upsample_grp_kernel(const float* __restri
   }
 }
 
-extern "C" int avc_upsample_step(const float* rays_o, const float* rays_d, const float* z_in, const float* sdf_in,
-                                 int R, int n, int m, float inv_s, float* z_out, float* sdf_out, float* z_new,
-                                 int* slot_new, void* stream) {
+// lanes_per_ray: 0 = chosen from (n, m) -- 16 lanes per ray for n + m <= 64, 32 for n + m <= 128, a whole wavefront otherwise; 64 = one
+// wavefront per ray for every n (the A/B partner and the cross-check of the tests).  The switch is an argument, not library state.
+extern "C" int avc_upsample_step_lanes(const float* rays_o, const float* rays_d, const float* z_in, const float* sdf_in,
+                                       int R, int n, int m, float inv_s, float* z_out, float* sdf_out, float* z_new,
+                                       int* slot_new, int lanes_per_ray, void* stream) {
   if (n > MAXS || m > 64 || n + m > MAXS || n < 2) { avc_set_error("avc_upsample_step: need 2 <= n, n+m <= 256, m <= 64"); return 1; }
+  if (lanes_per_ray != 0 && lanes_per_ray != 64) { avc_set_error("avc_upsample_step_lanes: lanes_per_ray is 0 (automatic) or 64"); return 1; }
   if (R <= 0) return 0;
-  // AVC_UPSAMPLE_GROUP=0 in the environment: one wavefront per ray for every n (the A/B partner and the cross-check of the tests)
-  const char* e = getenv("AVC_UPSAMPLE_GROUP");
-  const bool grouped = !(e && e[0] == '0') && m <= 16;
+  const bool grouped = lanes_per_ray == 0 && m <= 16;
   if (grouped && n + m <= 64)
     hipLaunchKernelGGL(upsample_grp_kernel<16>, dim3((R + 15) / 16), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, z_in, sdf_in, R, n, m,
                        inv_s, z_out, sdf_out, z_new, slot_new);
@@ -303,6 +304,11 @@ extern "C" int avc_upsample_step(const float* rays_o, const float* rays_d, const
     hipLaunchKernelGGL(upsample_kernel, dim3((R + RPB - 1) / RPB), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, z_in,
                        sdf_in, R, n, m, inv_s, z_out, sdf_out, z_new, slot_new);
   return avc_check_launch("avc_upsample_step");
+}
+extern "C" int avc_upsample_step(const float* rays_o, const float* rays_d, const float* z_in, const float* sdf_in,
+                                 int R, int n, int m, float inv_s, float* z_out, float* sdf_out, float* z_new,
+                                 int* slot_new, void* stream) {
+  return avc_upsample_step_lanes(rays_o, rays_d, z_in, sdf_in, R, n, m, inv_s, z_out, sdf_out, z_new, slot_new, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------

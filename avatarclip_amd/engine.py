@@ -214,7 +214,11 @@ class Engine:
     # Role-specialised backward (csrc/avc_bwd_ring.hip): the abar tiles of the middle SDF layers are handed from the backward sweeps
     # to accumulator-owning consumer workgroups of the same XCD through an L2-resident ring instead of through the G region.
     # RING_CPT = consumer workgroups per (XCD, product), RING_SLOTS = ring slots (128 KiB each for the full nets) per (XCD, product).
-    SDF_BIAS_FP32 = os.environ.get("AVC_SDF_BIAS_FP32", "0") != "0"
+    # the sdf-bias gradient (= sum of d_sdf over all points, a heavily cancelling sum: the eikonal term pulls both ways) from the fp32
+    # cotangent tensor instead of from the hi + lo bf16 tile: ONE reduction per backward.  The tile path measured 0.03 % on the 512^2
+    # fixture, but a cancelling sum's relative error grows as the sum approaches zero (late in training, when eikonal and mask terms
+    # balance), and the reference accumulates this gradient in fp32 -- so the override is ON; AVC_SDF_BIAS_FP32=0 for the A/B.
+    SDF_BIAS_FP32 = os.environ.get("AVC_SDF_BIAS_FP32", "1") != "0"
     RING = os.environ.get("AVC_BWD_RING", "0") != "0"
     RING_CPT = int(os.environ.get("AVC_RING_CPT", "2"))
     RING_SLOTS = int(os.environ.get("AVC_RING_SLOTS", "6"))
@@ -405,8 +409,10 @@ class Engine:
         sdf_out = torch.empty(R, n + m, device=self.device, dtype=torch.float32)
         z_new = torch.empty(R, m, device=self.device, dtype=torch.float32)
         slot = torch.empty(R, m, device=self.device, dtype=torch.int32)
-        L.check(self.lib.avc_upsample_step(L.ptr(rays_o), L.ptr(rays_d), L.ptr(z), L.ptr(sdf), R, n, m, float(inv_s),
-                                           L.ptr(z_out), L.ptr(sdf_out), L.ptr(z_new), L.ptr(slot), L.stream()),
+        # AVC_UPSAMPLE_GROUP=0: one wavefront per ray for every n (A/B partner and cross-check of the grouped kernels), read HERE per call
+        lanes = 64 if os.environ.get("AVC_UPSAMPLE_GROUP", "1") == "0" else 0
+        L.check(self.lib.avc_upsample_step_lanes(L.ptr(rays_o), L.ptr(rays_d), L.ptr(z), L.ptr(sdf), R, n, m, float(inv_s),
+                                                 L.ptr(z_out), L.ptr(sdf_out), L.ptr(z_new), L.ptr(slot), lanes, L.stream()),
                 "avc_upsample_step")
         return z_out, sdf_out, z_new, slot
 

@@ -32,6 +32,7 @@ class _Ring:
         self.buf = torch.empty(self.SLOTS, self.WIDTH, dtype=torch.float64).pin_memory()
         self.buf32 = torch.empty(self.SLOTS, self.WIDTH, dtype=torch.float32).pin_memory()   # float32 values travel as float32: no conversion launch
         self.events = [None] * self.SLOTS
+        self.slot_locks = [threading.Lock() for _ in range(self.SLOTS)]
         self.i = 0
 
     def put(self, a, dtype):
@@ -39,20 +40,24 @@ class _Ring:
         with _lock:
             slot = self.i % self.SLOTS
             self.i += 1
-        ev = self.events[slot]
-        if ev is not None:
-            ev.synchronize()
-        if dtype == torch.float32:
-            row = self.buf32[slot, :n]
-            row.copy_(torch.from_numpy(a.reshape(-1).astype(np.float32)))
-        else:
-            row = self.buf[slot, :n]
-            row.copy_(torch.from_numpy(a.reshape(-1)))
-        with torch.cuda.device(self.device):     # the copy AND its guard event go to this device's current stream
-            out = row.to(self.device, non_blocking=True).to(dtype).reshape(a.shape)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
-        self.events[slot] = ev
+        # the whole wait -> fill -> copy -> record sequence of a slot is one critical section: with the helper-thread prefetch two
+        # threads can wrap the ring onto the same slot (SLOTS uploads by one during the other's fill), and the second must neither
+        # overwrite the pinned row before its copy has been issued nor miss the event that guards it
+        with self.slot_locks[slot]:
+            ev = self.events[slot]
+            if ev is not None:
+                ev.synchronize()
+            if dtype == torch.float32:
+                row = self.buf32[slot, :n]
+                row.copy_(torch.from_numpy(a.reshape(-1).astype(np.float32)))
+            else:
+                row = self.buf[slot, :n]
+                row.copy_(torch.from_numpy(a.reshape(-1)))
+            with torch.cuda.device(self.device):     # the copy AND its guard event go to this device's current stream
+                out = row.to(self.device, non_blocking=True).to(dtype).reshape(a.shape)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+            self.events[slot] = ev
         return out
 
 

@@ -17,6 +17,7 @@ _SIGS = {
     "avc_num_offsets": (c_int, []),
     "avc_sdf_forward": (c_int, [c_int, P, P, P, P, c_int, c_int, c_long, P, P, P, P, P, c_int, P]),
     "avc_upsample_step": (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, P, P, P, P, P]),
+    "avc_upsample_step_lanes": (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, P, P, P, P, c_int, P]),
     "avc_render_points_fwd": (c_int, [c_int, P, P, P, P, c_int, c_int, c_float, c_long, P, P, P, P, P, P, c_long, P, P]),
     "avc_fwd_scratch_bytes_per_wave": (c_long, [c_int]),
     "avc_composite_fwd": (c_int, [P, P, P, P, P, P, c_int, c_int, P, c_float, c_float, P, c_int, P, P, P, P, P, P, P, P, P, P]),

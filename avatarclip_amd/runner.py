@@ -452,13 +452,27 @@ class Runner:
         return self._make_view_side(iter_i, camera)
 
     # ---- the next iteration's view, prepared beside this iteration's CLIP pass
+    def _prefetch_allowed(self, iter_i):
+        """The camera of iteration i + 1 may be drawn inside iteration i only when NOTHING draws from the host's numpy generator between
+        the two in main.py's order: not when the validation hooks fire after this iteration (validate_image picks a random view,
+        main.py:741-744), not on the last iteration of the run or at the reference's iter_i == 30010 break (a left-over view would have
+        consumed draws the reference never makes).  Off unless AVC_PREFETCH_VIEW=1."""
+        if (self.device.type != "cuda" or os.environ.get("AVC_PREFETCH_VIEW", "0") != "1" or os.environ.get("AVC_OVERLAP_HEAD", "1") == "0"):
+            return False
+        nxt = self.iter_step + 1          # the step count the hooks of THIS iteration will see
+        if (self.val_freq > 0 and nxt % self.val_freq == 0) or (self.val_mesh_freq > 0 and nxt % self.val_mesh_freq == 0):
+            return False
+        return nxt < self.end_iter and iter_i + 1 != 30010
+
     def prefetch_view(self, iter_i, after=None):
         """Start make_view(iter_i) for the NEXT iteration on the side stream.  The view depends on nothing the optimiser writes, and
         its ~100-140 small kernels (camera, prior rasterisation, rays; 1.0-1.3 ms of GPU time) fit beside the only other stretch of
         small kernels in the iteration -- the CLIP pass, 24-96 workgroups on a 256-CU chip -- whereas beside the persistent MLP kernels
         nothing becomes resident (profiles/r03_side_stream.txt, r04_ab_kernels.txt).  clip_loss() calls this right before it launches
         CLIP, when every numpy draw of the current iteration (background, light, ambience) has been made: the camera of iteration
-        i + 1 is drawn HERE, in the caller's thread, exactly where main.py:348-358 would draw it next, so the draw order is unchanged.
+        i + 1 is drawn HERE, in the caller's thread, exactly where main.py:348-358 would draw it next -- clip_loss skips the prefetch on
+        the iterations where something else draws in between (_prefetch_allowed: validation hooks, end of the run) -- so the draw order is
+        unchanged.
         `after` = an event on the main stream the side stream waits for (the end of the render + shading work), so that the view's
         kernels start when the GPU reaches CLIP.  In silhouette mode make_view makes two round trips to the host (pixel counts -> ray
         grid -> ray count): a helper thread does that waiting.  Injected cameras (tests) bypass it.  OPT-IN (AVC_PREFETCH_VIEW=1):
@@ -685,7 +699,7 @@ class Runner:
                          np.random.uniform(0, 0.2))
         else:
             comp = self.shade_and_scatter(render_out, view, choice_i, background_rgb)
-        if camera is None and self.device.type == "cuda":
+        if camera is None and self._prefetch_allowed(iter_i):
             # every host draw of this iteration is made: the next view is prepared beside the CLIP pass that follows
             reached = torch.cuda.Event()
             reached.record(torch.cuda.current_stream(self.device))
@@ -698,6 +712,9 @@ class Runner:
         return loss, parts
 
     def train_clip_iteration(self, iter_i, camera=None):
+        release = getattr(self.perceptor, "release_graphs", None)
+        if release is not None:
+            release()     # a graph-replayed encode_image of an earlier iteration that never reached backward (exception, probe call) does not hold its instance
         loss, parts = self.clip_loss(iter_i, camera)
         self.optimizer.zero_grad(set_to_none=self.grad_bucket is None)
         loss.backward()

@@ -55,7 +55,8 @@ class MeshPrior:
         self.light2 = torch.cat([light_ambient + light_directional * c.clamp(min=0),
                                  light_ambient + light_directional * (-c).clamp(min=0)]).contiguous()
         self.lib = L.load()
-        self._zbuf = self._ndc = None
+        self._zbufs = {}        # z-buffer scratch per HIP stream (the side-stream view preparation and main-stream validation renders never share one)
+        self._ndc = None
 
     @classmethod
     def from_obj(cls, path, **kw):
@@ -74,6 +75,27 @@ class MeshPrior:
         verts, _ = smpl_lbs.lbs(vs, rot, smpl["posedirs"], smpl["J_regressor"], smpl["parents"], smpl["lbs_weights"])
         return cls(verts[0].detach().cpu().numpy(), smpl["faces"], **kw)
 
+    def _zbuf_for(self, need):
+        """The rasteriser's persistent scratch (64-bit (depth, face) keys + the large-face list): all bits set = empty, and every
+        successful call LEAVES it that way (the resolve launch restores the keys it read), which is what saves a 2-MB fill per view.
+        One buffer per HIP stream -- the launches of one render are ordered by their stream, two streams must not interleave on one
+        z-buffer -- dropped (and refilled on the next call) whenever a launch of the sequence reports an error, so that stale keys of
+        an interrupted render cannot leak into later priors and silhouette masks."""
+        key = (L.stream(), need)
+        z = self._zbufs.get(key)
+        if z is None:
+            for k in [k for k in self._zbufs if k[0] == key[0]]:
+                del self._zbufs[k]
+            z = self._zbufs[key] = torch.full((need,), 255, dtype=torch.uint8, device=self.device)
+        return z
+
+    def _checked(self, status, what):
+        try:
+            L.check(status, what)
+        except Exception:
+            self._zbufs.clear()          # the z-buffer of an interrupted render is not empty any more: never reuse it
+            raise
+
     @torch.no_grad()
     def render_grey(self, eye, direction, rgb_flipped=False):
         """nr.Renderer(camera_mode='look')(vertices, faces, ones) -> [S,S] grey image (before the x flip)"""
@@ -91,15 +113,13 @@ class MeshPrior:
         if FUSED_PRIOR:      # projection + rasteriser + 2 x 2 average (+ x flip + channels) in four launches (csrc/avc_raster.hip)
             ch = 3 if rgb_flipped else 1
             out = torch.empty((S, S, 3) if rgb_flipped else (S, S), device=dev, dtype=torch.float32)
-            need = self.lib.avc_rasterize_scratch_bytes(self.faces2.shape[0], 2 * S)
-            if self._zbuf is None or self._zbuf.numel() != need:
-                self._zbuf = torch.full((need,), 255, dtype=torch.uint8, device=dev)
+            zbuf = self._zbuf_for(self.lib.avc_rasterize_scratch_bytes(self.faces2.shape[0], 2 * S))
             if self._ndc is None:
                 self._ndc = torch.empty_like(self.v_world)
                 self._faces2_i32 = self.faces2.to(torch.int32).contiguous()
-            L.check(self.lib.avc_rasterize_mesh(L.ptr(self.v_world), self.v_world.shape[0], L.ptr(self._faces2_i32), self.faces2.shape[0], L.ptr(cam),
-                                                self.width, L.ptr(self.light2), S, self.near, self.far, L.ptr(self._ndc), L.ptr(out),
-                                                int(rgb_flipped), ch, L.ptr(self._zbuf), L.stream()), "avc_rasterize_mesh")
+            self._checked(self.lib.avc_rasterize_mesh(L.ptr(self.v_world), self.v_world.shape[0], L.ptr(self._faces2_i32), self.faces2.shape[0], L.ptr(cam),
+                                                      self.width, L.ptr(self.light2), S, self.near, self.far, L.ptr(self._ndc), L.ptr(out),
+                                                      int(rgb_flipped), ch, L.ptr(zbuf), L.stream()), "avc_rasterize_mesh")
             return out
         v = (self.v_world - cam[:3]) @ cam[3:].reshape(3, 3).t()
         ndc = torch.stack([v[:, 0] / v[:, 2] / self.width, v[:, 1] / v[:, 2] / self.width, v[:, 2]], dim=1)   # perspective.py
@@ -107,11 +127,9 @@ class MeshPrior:
         fz = ndc[self.faces2].reshape(-1, 9).contiguous()
         S2 = 2 * self.image_size                                    # anti_aliasing=True
         img = torch.empty(S2, S2, device=dev, dtype=torch.float32)
-        need = self.lib.avc_rasterize_scratch_bytes(fz.shape[0], S2)
-        if self._zbuf is None or self._zbuf.numel() != need:        # (all bits set = empty; every call leaves it that way)
-            self._zbuf = torch.full((need,), 255, dtype=torch.uint8, device=dev)
-        L.check(self.lib.avc_rasterize_faces(L.ptr(fz), L.ptr(self.light2), fz.shape[0], S2, self.near, self.far, L.ptr(img),
-                                             L.ptr(self._zbuf), L.stream()), "avc_rasterize_faces")
+        zbuf = self._zbuf_for(self.lib.avc_rasterize_scratch_bytes(fz.shape[0], S2))
+        self._checked(self.lib.avc_rasterize_faces(L.ptr(fz), L.ptr(self.light2), fz.shape[0], S2, self.near, self.far, L.ptr(img),
+                                                   L.ptr(zbuf), L.stream()), "avc_rasterize_faces")
         grey = torch.nn.functional.avg_pool2d(img[None, None], kernel_size=2, stride=2)[0, 0]
         return grey.flip(1)[..., None].repeat(1, 1, 3) if rgb_flipped else grey
 

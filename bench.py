@@ -317,8 +317,18 @@ def main():
         want = os.environ.get("AVC_ASSERT_DIST")
         assert not want or want == be, "process group backend %s, expected %s" % (be, want)
 
+    torch.cuda.reset_peak_memory_stats(dev)
+    free0, total0 = torch.cuda.mem_get_info(dev)
     runner = build_runner(args.res, args.spp, args.small, dev)
     dt, per_kernel = timed_steps(runner, args.steps, args.warmup, dev, args.sync_debug)
+    # footprint of the headline run: the operand panels are sized from the memory that was FREE when the run started (Engine.plan:
+    # min(AVC_PANEL_GIB, 80 % of the free HBM); the G slab is halved before anything else gives), so the numbers below change with it
+    eng0 = runner.renderer.engine
+    chunk0, slab0 = eng0.plan(args.res * args.res, args.spp)
+    memory = {"peak_hbm_gib": torch.cuda.max_memory_allocated(dev) / 2 ** 30, "free_at_start_gib": free0 / 2 ** 30, "device_total_gib": total0 / 2 ** 30,
+              "panel_budget_gib": min(eng0.PANEL_BYTES_BUDGET, free0 * 8 // 10) / 2 ** 30, "rays_per_chunk": chunk0, "rays_per_slab": slab0,
+              "gradient_slabs_per_step": -(-args.res * args.res // max(1, slab0)), "forward_reruns_in_backward": chunk0 < args.res * args.res}
+    del eng0
 
     out = None
     if rank == 0:
@@ -335,6 +345,8 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "iters_per_sec": args.steps / dt,
+            "peak_hbm_gib": memory["peak_hbm_gib"],
+            "memory": memory,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

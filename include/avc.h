@@ -42,6 +42,11 @@ int avc_sdf_forward(int net, const float* pts, const float* rays_o, const float*
 int avc_upsample_step(const float* rays_o, const float* rays_d, const float* z_in, const float* sdf_in, int R,
                       int n, int m, float inv_s, float* z_out, float* sdf_out, float* z_new, int* slot_new,
                       void* stream);
+/* the same with the work distribution as an argument: lanes_per_ray = 0 (chosen from n and m: 16 / 32 lanes per ray for n + m <= 64 /
+ * 128, avc_upsample_step's choice) or 64 (one wavefront per ray: the cross-check of the grouped kernels) */
+int avc_upsample_step_lanes(const float* rays_o, const float* rays_d, const float* z_in, const float* sdf_in, int R,
+                            int n, int m, float inv_s, float* z_out, float* sdf_out, float* z_new, int* slot_new,
+                            int lanes_per_ray, void* stream);
 
 /* sdf_network(pts) + sdf_network.gradient(pts) + color_network(...) of render_core (renderer.py:221-232) at the
  * section mid-points of z[R,S] (or at pts[N,3]): sdf[N], normal[N,3] (= d sdf/dx), rgb[N,6] = sigmoid([rgb ; extra]). */

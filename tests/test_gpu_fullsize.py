@@ -130,12 +130,18 @@ def _pick_rays(eng, R, n, spp=64):
     return torch.tensor(sorted(pick), dtype=torch.long)
 
 
-def _dense_gradient_errors(dev, nsel, two_slabs, monkeypatch):
+def _dense_gradient_errors(dev, nsel, two_slabs, monkeypatch, coherent=False):
     """Dense gradient of ONE 512 x 512 x 64-spp training launch for a loss supported on `nsel` rays (zero cotangents elsewhere) against
-    the oracle's autograd on those rays.  Returns (loss, oracle loss, [(name, rel, cos, tiny)])."""
+    the oracle's autograd on those rays.  Returns (loss, oracle loss, [(name, rel, cos, tiny)]).  coherent = False: independent normal
+    coefficients per ray (the gradient is itself a random sum over rays); True: the SAME coefficients on every ray, as in a real loss
+    (the gradient grows with the number of rays, rounding noise only with its square root)."""
+    import gc
     from avatarclip_amd.engine import Engine
+    gc.collect()                 # an earlier case's engine (180 GiB of operand panels) must be gone before this one plans its buffers
+    torch.cuda.empty_cache()
     if two_slabs:
         monkeypatch.setattr(Engine, "SLAB_BLOCKS", 256 * 1024)      # two slabs (the default is one slab for this ray set): the boundary is part of the test
+        monkeypatch.setattr(Engine, "SDF_BIAS_FP32", False)         # ... and so is the hi + lo d_sdf tile: the sdf bias out of the products, no fp32 side path
     sdf, col, var, ren = _full_renderer(dev)
     with torch.no_grad():   # off the degenerate initialisation (the PE columns of layer 0 are zero there), as oracle/gen_golden.py does
         gp = torch.Generator().manual_seed(11)
@@ -154,6 +160,9 @@ def _dense_gradient_errors(dev, nsel, two_slabs, monkeypatch):
     gc = torch.Generator().manual_seed(4)
     c1, c2, cw = torch.randn(nsel, 3, generator=gc), torch.randn(nsel, 3, generator=gc), torch.randn(nsel, 1, generator=gc)
     cn = torch.randn(nsel, 3, generator=gc) * 0.3
+    if coherent:
+        c1, c2 = torch.tensor([[0.7, -0.4, 0.5]]).expand(nsel, 3), torch.tensor([[-0.3, 0.8, 0.6]]).expand(nsel, 3)
+        cw, cn = torch.full((nsel, 1), 0.9), torch.tensor([[0.2, -0.3, 0.25]]).expand(nsel, 3)
 
     def loss_of(out, sel, t):
         nsum = (out["gradients"][sel] * out["weights"][sel][..., None]).sum(1)
@@ -197,9 +206,11 @@ def test_fullsize_dense_gradient_of_256_rays_matches_the_oracles_autograd(monkey
     fields.py:72-107,154-185): the loss is supported on the same 256 rays as the forward test (first / last ray, the rays at every
     4-GiB boundary of the F panel region, random ones) and has zero cotangents everywhere else, so the dense gradient that comes out
     of the two-slab, 110-GiB backward pass (avc_render_points_bwd + avc_weight_grad_all over 16.8 M points, panel offsets far beyond
-    2^32) must equal the autograd gradient of the oracle rendering just those 256 rays.  SURVEY 8d gate: 1e-2 per tensor; at these
-    16 K points the colour tensors get 1.5e-2 -- their error is sampling noise that falls with the number of points, which
-    test_colour_gradient_error_falls_with_the_number_of_points measures and then holds to 1e-2 at 262 K points.  The loss takes colours,
+    2^32) must equal the autograd gradient of the oracle rendering just those 256 rays.  SURVEY 8d gate: 1e-2 per tensor; the colour
+    tensors get 1.5e-2 HERE because this loss has independent random coefficients per ray: its gradient is a random sum that grows like
+    sqrt(rays), exactly like the per-point rounding noise (ReLU sign flips of f16-operand pre-activations), so their ratio -- 1.0-1.2 % on
+    colour layer 0 -- is a property of the probe and does not shrink with more rays (1.16 % at 256 rays, 1.07 % at 4 096).  Under a loss with
+    one sign per term, test_dense_gradient_under_a_coherent_loss_at_16k_and_262k_points holds EVERY tensor to 5e-3.  The loss takes colours,
     the CLIP colours, the weight sums and the normals (sum_i w_i n_i, main.py:428) -- not the eikonal term, whose normaliser runs over
     all rays of the view."""
     dev = torch.device("cuda")
@@ -209,8 +220,8 @@ def test_fullsize_dense_gradient_of_256_rays_matches_the_oracles_autograd(monkey
     bad = []
     for name, rel, cos, tiny in rows:
         # SDF tensors: SURVEY's 1e-2 (measured 0.01-0.31 %, the sdf bias -- a heavily cancelling sum -- 0.03 % out of the hi + lo d_sdf
-        # tile).  Colour tensors at 16 K points: 1.5e-2 (layer 0 sits at 1.0-1.2 %: ReLU units whose f16-operand pre-activation has the
-        # other sign than the fp32 one flip their whole contribution -- noise, see the test below)
+        # tile).  Colour tensors: 1.5e-2 (layer 0 sits at 1.0-1.2 % against this random-sign loss -- zero-mean noise measured against a
+        # zero-mean signal; 0.2 % against a coherent one, see the test below)
         gate = 2e-2 if tiny else (1.5e-2 if name.startswith("col.") else 1e-2)
         if not (rel < gate and cos > 0.9995):
             bad.append((name, rel, cos))
@@ -218,25 +229,28 @@ def test_fullsize_dense_gradient_of_256_rays_matches_the_oracles_autograd(monkey
 
 
 @gpu
-def test_colour_gradient_error_falls_with_the_number_of_points(monkeypatch):
-    """is the 1.0-1.2 % of the colour tensors at 16 K points sampling noise (ReLU sign flips of f16-operand
-    pre-activations, rounding of cancelling sums) or a bias?  Noise falls like 1 / sqrt(points), a bias does not.  The same launch, the
-    same weights, the same kind of loss on 256 rays (16 K points) and on 4 096 rays (262 K points): every colour tensor's relative
-    error must fall by at least 2 x (4 x for pure noise), and at 262 K points EVERY tensor -- colour tensors included, no carve-out --
-    must meet SURVEY 8d's 1e-2 (fields.py:154-185 under main.py:537)."""
+def test_dense_gradient_under_a_coherent_loss_at_16k_and_262k_points(monkeypatch):
+    """is the 1.0-1.2 % of the colour tensors in the random-coefficient fixtures sampling noise (ReLU sign flips of
+    f16-operand pre-activations, rounding of cancelling sums) or a per-point bias?  Noise grows like sqrt(points), a bias like the
+    points -- but that only shows against a SIGNAL that grows like the points.  With independent random coefficients per ray (the
+    256-ray test above, the golden fixtures) the gradient is itself a random sum, signal and noise both grow like sqrt(rays), and the
+    ratio cannot move: measured 1.16 % at 256 rays, 1.07 % at 4 096 on col.lin0.weight_v (profiles/r05_gradient_noise.md).  This test
+    gives every ray the SAME coefficients, as every real loss does (main.py:489-534: one sign per term): the same launch, the same
+    weights, 256 rays (16 K points) and 4 096 rays (262 K points).  A per-point bias of the ReLU masks would show here as >= 1 % at both
+    sizes.  Measured: EVERY tensor, the colour tensors included, sits at 0.003-0.25 % at BOTH sizes -- what is left is the one error that
+    is identical for all points, the f16 / bf16 rounding of the weights themselves (2^-9 = 0.2 % for bf16).  Gate: 5e-3 per tensor at both
+    sizes, no carve-out (SURVEY 8d asks 1e-2; fields.py:154-185 under main.py:537)."""
     dev = torch.device("cuda")
-    _, _, small = _dense_gradient_errors(dev, 256, False, monkeypatch)
-    loss, loss_ref, large = _dense_gradient_errors(dev, 4096, False, monkeypatch)
-    assert abs(loss - loss_ref) < 2e-3 * max(1.0, abs(loss_ref))
-    e256 = {n: r for n, r, _, _ in small}
+    rows = {}
+    for nsel in (256, 4096):
+        loss, loss_ref, rows[nsel] = _dense_gradient_errors(dev, nsel, False, monkeypatch, coherent=True)
+        assert abs(loss - loss_ref) < 2e-3 * max(1.0, abs(loss_ref))
+    e256 = {n: r for n, r, _, _ in rows[256]}
     bad = []
-    for name, rel, cos, tiny in large:
-        ratio = e256[name] / max(rel, 1e-12)
-        print("  %-22s 256 rays %.3e -> 4096 rays %.3e  (x %.2f)" % (name, e256[name], rel, ratio))
-        if not (rel < 1e-2 and cos > 0.9995):
-            bad.append((name, "gate", rel, cos))
-        if name.startswith("col.") and e256[name] > 3e-3 and ratio < 2.0:
-            bad.append((name, "does not fall", e256[name], rel))
+    for name, rel, cos, tiny in rows[4096]:
+        print("  %-22s 256 rays %.3e -> 4096 rays %.3e" % (name, e256[name], rel))
+        if not (rel < 5e-3 and e256[name] < 5e-3 and cos > 0.9995):
+            bad.append((name, e256[name], rel, cos))
     assert not bad, bad
 
 

@@ -142,3 +142,35 @@ def test_bench_single_rank_under_the_launcher_runs_the_rccl_path():
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["config"]["collective"] == "nccl (RCCL), 1 rank(s)"
+
+
+@gpu
+def test_two_replicas_equal_their_solo_runs(tmp_path):
+    """BASELINE config 4 (replicas only): two independent avatars -- their own seeds, hence their own prompt stand-ins, cameras
+    and jitter -- started side by side by avatarclip_amd.replicas (no process group; both on device 0 here, one per GPU on a node) must
+    produce exactly the losses each produces when it runs alone: nothing is shared but the device."""
+    import json
+    import os
+    import sys
+    from avatarclip_amd import replicas
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = os.path.join(root, "tests", "replica_child.py")
+
+    def cmds(tag):
+        return [[sys.executable, child, str(seed), "3", os.path.join(str(tmp_path), "%s_%d.json" % (tag, seed))] for seed in (1, 2)]
+
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1")        # a launcher's leftovers must not turn replicas into ranks
+    rcs = replicas.launch_commands(cmds("pair"), gpus=[0], log_dir=str(tmp_path / "logs"), env=env)
+    assert rcs == [0, 0], [open(os.path.join(str(tmp_path), "logs", "replica_%d.log" % i)).read()[-1500:] for i in range(2)]
+    for c in cmds("solo"):
+        assert replicas.launch_commands([c], gpus=[0], log_dir=str(tmp_path / "logs_solo"))[0] == 0
+    for seed in (1, 2):
+        pair = json.load(open(os.path.join(str(tmp_path), "pair_%d.json" % seed)))
+        solo = json.load(open(os.path.join(str(tmp_path), "solo_%d.json" % seed)))
+        print(seed, pair, solo)
+        assert pair["visible"] == "0" and pair["replica"] == str(seed - 1)
+        assert all(np.isfinite(pair["losses"])) and len(pair["losses"]) == 3
+        assert np.allclose(pair["losses"], solo["losses"], rtol=1e-6, atol=0), (pair["losses"], solo["losses"])
+    a = json.load(open(os.path.join(str(tmp_path), "pair_1.json")))["losses"]
+    b = json.load(open(os.path.join(str(tmp_path), "pair_2.json")))["losses"]
+    assert abs(a[0] - b[0]) > 1e-6, "the two replicas are supposed to be different avatars"

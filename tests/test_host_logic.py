@@ -212,6 +212,17 @@ def test_panel_plan_arithmetic():
     # tiny ray sets are never cut
     assert plan_panels(1, 64, 1 << 26, blk_f, blk_g, 256 * 1024, 32 * 1024) == (1, 1)
     assert plan_panels(33, 64, 1 << 26, blk_f, blk_g, 256 * 1024, 32 * 1024) == (33, 33)
+    # one gradient slab or two is decided by the memory that is FREE, not by a constant (Engine.plan: budget = min(AVC_PANEL_GIB,
+    # 80 % of the free HBM); default slab = 512 Ki blocks): an empty 288-GB MI355X takes 512^2 x 64 spp in one 92-GiB slab
+    # (87 + 92 = 179 GiB), the same device with 100 GB held by somebody else falls back to two 46-GiB slabs, with 160 GB held to
+    # sixteen, and the view is still ONE forward chunk
+    full_dev = int(0.8 * 268 * gib)
+    assert plan_panels(512 * 512, 64, min(224 * gib, full_dev), blk_f, blk_g, 512 * 1024, 32 * 1024) == (262144, 262144)
+    assert plan_panels(512 * 512, 64, int(0.8 * 175 * gib), blk_f, blk_g, 512 * 1024, 32 * 1024) == (262144, 131072)
+    assert plan_panels(512 * 512, 64, int(0.8 * 150 * gib), blk_f, blk_g, 512 * 1024, 32 * 1024) == (262144, 65536)
+    assert plan_panels(512 * 512, 64, int(0.8 * 125 * gib), blk_f, blk_g, 512 * 1024, 32 * 1024) == (262144, 16384)
+    chunk, slab = plan_panels(512 * 512, 64, int(0.8 * 100 * gib), blk_f, blk_g, 512 * 1024, 32 * 1024)   # below ~96 GiB the view is cut
+    assert chunk < 262144 and nbytes(chunk, slab, 64) <= 80 * gib
 
 
 def test_softplus_direct_form_and_relu_mask_bit_order_restated():

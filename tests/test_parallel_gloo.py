@@ -118,3 +118,30 @@ def test_queue_oversubscription_is_reported_only_when_ranks_share_a_device(monke
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "2")
     assert parallel.check_queue_oversubscription(8, 1, said.append) is None
     assert parallel.check_queue_oversubscription(8, 0, said.append) is None          # no device visible (CPU tests)
+
+
+def test_replica_layout_and_environment(tmp_path, monkeypatch):
+    """avatarclip_amd.replicas (BASELINE config 4): device round-robin + NUMA core slices (pure), and the children's environment -- one
+    visible device each, no rank variables, the hardware-queue cap when replicas share a device, logs, exit codes."""
+    import json
+    import sys
+    from avatarclip_amd import replicas
+    cpus = {0: list(range(0, 64)), 1: list(range(64, 128))}
+    lay = replicas.plan(8, list(range(8)), list(range(128)), [0, 0, 0, 0, 1, 1, 1, 1], cpus)
+    assert [g for g, _ in lay] == list(range(8))
+    assert all(len(c) == 16 for _, c in lay) and set(lay[5][1]) <= set(cpus[1]) and set(lay[2][1]) <= set(cpus[0])
+    lay = replicas.plan(4, [2, 3], list(range(128)), [0, 0, 1, 1], cpus)              # four replicas on two devices
+    assert [g for g, _ in lay] == [2, 3, 2, 3] and all(set(c) <= set(cpus[1]) for _, c in lay) and len(set(sum((c for _, c in lay), []))) == 64
+    assert replicas.plan(0, [0], [0]) == []
+    prog = "import os, json, sys; json.dump({k: os.environ.get(k) for k in ('HIP_VISIBLE_DEVICES', 'RANK', 'WORLD_SIZE', 'AVC_REPLICA', 'GPU_MAX_HW_QUEUES')}, open(sys.argv[1], 'w')); sys.exit(int(sys.argv[2]))"
+    outs = [str(tmp_path / ("r%d.json" % i)) for i in range(9)]
+    cmds = [[sys.executable, "-c", prog, outs[i], "3" if i == 4 else "0"] for i in range(9)]
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    rcs = replicas.launch_commands(cmds, gpus=[0, 1], log_dir=str(tmp_path / "logs"), env=dict(os.environ, RANK="3", WORLD_SIZE="8"))
+    assert rcs == [0, 0, 0, 0, 3, 0, 0, 0, 0]
+    for i in range(9):
+        e = json.load(open(outs[i]))
+        assert e["HIP_VISIBLE_DEVICES"] == str(i % 2) and e["RANK"] is None and e["WORLD_SIZE"] is None and e["AVC_REPLICA"] == str(i)
+        assert e["GPU_MAX_HW_QUEUES"] == "2"          # 5 processes x 4 queues on one device would oversubscribe it
+        assert os.path.exists(str(tmp_path / "logs" / ("replica_%d.log" % i)))
+    assert replicas.main(["--confs", "/nonexistent/a.conf", "--gpus", "0", "--log_dir", str(tmp_path / "l2"), "--mode", "train"]) == 1

@@ -7,8 +7,14 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, os.environ.get("AVC_LIB_NAME", "libavc.so"))
-SOURCES = ["avc_core.hip", "avc_mlp_fwd.hip", "avc_mlp_bwd.hip", "avc_bwd_ring.hip", "avc_wgrad.hip", "avc_rays.hip", "avc_vit.hip", "avc_vit_attn.hip", "avc_vit_gemm.hip", "avc_mcubes.hip", "avc_raster.hip", "avc_params.hip", "avc_glue.hip"]
-HEADERS = ["avc_common.h", "avc_stage.h", "avc_mlp.h", "avc_bwd_body.h", "avc_wgrad_body.h", "avc_offsets_gen.h", os.path.join("..", "..", "include", "avc.h")]
+# csrc/avc_bwd_ring.hip (the role-specialised backward of round 4, measured slower: profiles/r04_ring_handoff.md) is NOT part of
+# libavc.so; `build(ring=True)` / `python -m avatarclip_amd.build --ring` / AVC_WITH_RING=1 links it, with everything else, into
+# libavc_ring.so (include/avc_ring.h), which AVC_LIB_NAME=libavc_ring.so AVC_BWD_RING=1 selects.
+RING_SOURCE = "avc_bwd_ring.hip"
+RING_LIB = os.path.join(HERE, "libavc_ring.so")
+SOURCES = ["avc_core.hip", "avc_mlp_fwd.hip", "avc_mlp_bwd.hip", "avc_wgrad.hip", "avc_rays.hip", "avc_vit.hip", "avc_vit_attn.hip", "avc_vit_gemm.hip", "avc_mcubes.hip", "avc_raster.hip", "avc_params.hip", "avc_glue.hip"]
+HEADERS = ["avc_common.h", "avc_stage.h", "avc_mlp.h", "avc_bwd_body.h", "avc_wgrad_body.h", "avc_offsets_gen.h", os.path.join("..", "..", "include", "avc.h"),
+           os.path.join("..", "..", "include", "avc_ring.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"] + os.environ.get("AVC_EXTRA_FLAGS", "").split()
 
 
@@ -35,9 +41,12 @@ def _gen_offsets():
     mod.main()
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, ring: bool = False) -> str:
+    """libavc.so (or $AVC_LIB_NAME); ring=True: libavc_ring.so = the same objects + csrc/avc_bwd_ring.hip"""
     _gen_offsets()
-    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    ring = ring or os.environ.get("AVC_WITH_RING", "0") == "1"
+    target = RING_LIB if ring else LIB
+    srcs = [s for s in SOURCES + ([RING_SOURCE] if ring else []) if os.path.exists(os.path.join(CSRC, s))]
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, jobs = [], []
     for s in srcs:
@@ -57,10 +66,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB, objs):
-        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    return LIB
+    if jobs or force or _stale(target, objs):
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs)
+    return target
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, ring="--ring" in sys.argv))

@@ -327,6 +327,9 @@ class Engine:
         return self._grow("_gpanels", (nblk_slab + 1) * self.grad_tiles * 2048)
 
     def _ring_setup(self):
+        if not L.has_ring():
+            raise RuntimeError("AVC_BWD_RING=1 needs libavc_ring.so (python -m avatarclip_amd.build --ring; AVC_LIB_NAME=libavc_ring.so): the "
+                               "role-specialised backward is an experiment that is not part of libavc.so (include/avc_ring.h)")
         """buffers + pair tables of the role-specialised backward: (ctl, payload, partial, bias_partial, pb_tiles, pairs of the
         remaining weight-gradient launch, [(out_off, bias_off)] of the ring products)"""
         key = (self.RING_CPT, self.RING_SLOTS)

@@ -66,13 +66,16 @@ _SIGS = {
     "avc_resize_norm_bwd": (c_int, [P, c_int, c_int, c_int, P, P, P, P]),
     "avc_gen_rays": (c_int, [P, P, P, c_int, c_int, c_float, c_float, c_float, c_int, c_int, c_int, P, P, P, P, P, P, P]),
     "avc_chess_background": (c_int, [P, c_int, c_int, c_int, P, P]),
+}
+_OPTIONAL = {}
+# experimental entry points of libavc_ring.so (include/avc_ring.h): bound when the loaded library has them
+_RING_SIGS = {
     "avc_bwd_ring_ctl_bytes": (c_long, []),
     "avc_bwd_ring_payload_bytes": (c_long, [c_int, c_int, c_int]),
     "avc_bwd_ring_types": (c_int, [c_int]),
     "avc_render_points_bwd_ring": (c_int, [c_int, P, P, P, P, c_int, c_int, c_float, c_long, P, P, P, P, P, P, P, P, P, P,
                                            P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
 }
-_OPTIONAL = {}
 
 
 def lib_path():
@@ -94,8 +97,18 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in _RING_SIGS.items():
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib
+
+
+def has_ring():
+    """the loaded library is libavc_ring.so (csrc/avc_bwd_ring.hip linked in)"""
+    return hasattr(load(), "avc_render_points_bwd_ring")
 
 
 def register_optional(sigs):

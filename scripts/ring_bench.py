@@ -1,7 +1,8 @@
 """Round-4 development aid: the backward pair (backward sweeps + weight-gradient products) through the G region vs the role-specialised
 launch with the L2 ring (csrc/avc_bwd_ring.hip), event-timed, with the ring's own counters.
     python scripts/ring_bench.py [npts] [mode ...]      mode = plain | ring:<cpt>:<slots>
-Under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE the per-kernel counters say how many of the handed-off bytes reached HBM."""
+Under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE the per-kernel counters say how many of the handed-off bytes reached HBM.
+Since round 5 the ring kernel is not part of libavc.so: python -m avatarclip_amd.build --ring; AVC_LIB_NAME=libavc_ring.so python scripts/ring_bench.py ..."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from avatarclip_amd import fields, renderer

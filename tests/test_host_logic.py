@@ -121,14 +121,23 @@ def test_c_abi_exports_every_declared_symbol():
     from avatarclip_amd import build
     path = build.build()
     lib = ctypes.CDLL(path)
-    hdr = open(os.path.join(ROOT, "include", "avc.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    names = re.findall(r"\b(avc_\w+)\s*\(", hdr)
+
+    def declared(header):
+        hdr = open(os.path.join(ROOT, "include", header)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        return re.findall(r"\b(avc_\w+)\s*\(", hdr)
+    names = declared("avc.h")
     assert len(names) >= 14
     for n in names:
         assert hasattr(lib, n), n
     lib.avc_version.restype = ctypes.c_int
     assert lib.avc_version() >= 1
+    # the experimental header: its entry points live in libavc_ring.so ONLY (the product library does not carry the experiment)
+    ring_names = declared("avc_ring.h")
+    assert len(ring_names) == 4 and not any(hasattr(lib, n) for n in ring_names)
+    ring = ctypes.CDLL(build.build(ring=True))
+    for n in names + ring_names:
+        assert hasattr(ring, n), n
 
 
 def test_gaussian_blur_matches_depthwise_convolution():

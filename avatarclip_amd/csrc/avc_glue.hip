@@ -277,29 +277,55 @@ __global__ __launch_bounds__(GLUE_THREADS) void resize_norm_fwd_kernel(const flo
 #pragma unroll
   for (int c = 0; c < 3; ++c) out[(((long)b * 3 + c) * CLIP_RES + y) * CLIP_RES + x] = (v[c] - nm.mean[c]) * nm.istd[c];
 }
-// din [B,H,W,3] (zeroed by the launcher) += the transpose of the map above applied to dout [B,3,224,224]
+// din [B,H,W,3] = the transpose of the map above applied to dout [B,3,224,224], as a GATHER: one thread per input pixel adds up, in a
+// fixed order, the output pixels whose two-tap stencil touches it.  (Rounds 3-4 scattered with atomicAdd: correct, but the order of
+// the float additions -- hence the last bits of every pixel gradient, hence after Adam's sign-sensitive first steps the 5th digit of the
+// next losses -- changed from run to run; an iteration is now bit-reproducible, which is what lets "two replicas side by side equal
+// their solo runs" be asserted, tests/test_gpu_parallel.py.)
+// weight with which output index o feeds input index i (0 if it does not); both taps can land on the last input index
+__device__ __forceinline__ float tap_weight(int o, int i, int in_size, float scale) {
+  const Lerp l = lerp_of(o, in_size, scale);
+  return (l.i0 == i ? l.w0 : 0.f) + (l.i1 == i ? l.w1 : 0.f);
+}
+// output indices whose stencil can touch input index i: src = scale (o + 0.5) - 0.5 in (i - 1, i + 1), one index of margin either way
+__device__ __forceinline__ void tap_range(int i, int in_size, float scale, int& lo, int& hi) {
+  const float inv = 1.f / scale;
+  lo = (int)floorf(((float)i - 0.5f) * inv - 0.5f) - 1;
+  hi = (int)ceilf(((float)i + 1.5f) * inv - 0.5f) + 1;
+  if (i == 0 || lo < 0) lo = 0;
+  if (i == in_size - 1 || hi > CLIP_RES - 1) hi = CLIP_RES - 1;
+}
 __global__ __launch_bounds__(GLUE_THREADS) void resize_norm_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int B, int H, int W,
                                                                        Norm3 nm) {
-  const int idx = blockIdx.x * GLUE_THREADS + threadIdx.x;
-  if (idx >= B * CLIP_RES * CLIP_RES) return;
-  const int x = idx % CLIP_RES, y = (idx / CLIP_RES) % CLIP_RES, b = idx / (CLIP_RES * CLIP_RES);
-  float* ib = din + (long)b * H * W * 3;
-  float gv[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) gv[c] = dout[(((long)b * 3 + c) * CLIP_RES + y) * CLIP_RES + x] * nm.istd[c];
+  const long idx = (long)blockIdx.x * GLUE_THREADS + threadIdx.x;
+  if (idx >= (long)B * H * W) return;
+  const int x = (int)(idx % W), y = (int)((idx / W) % H), b = (int)(idx / ((long)W * H));
+  const float* ob = dout + (long)b * 3 * CLIP_RES * CLIP_RES;
+  float acc[3] = {0.f, 0.f, 0.f};
   if (H == CLIP_RES && W == CLIP_RES) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) ib[((long)y * W + x) * 3 + c] = gv[c];
-    return;
-  }
-  const Lerp ly = lerp_of(y, H, (float)H / CLIP_RES), lx = lerp_of(x, W, (float)W / CLIP_RES);
+    for (int c = 0; c < 3; ++c) acc[c] = ob[((long)c * CLIP_RES + y) * CLIP_RES + x];
+  } else {
+    const float sy = (float)H / CLIP_RES, sx = (float)W / CLIP_RES;
+    int y0, y1, x0, x1;
+    tap_range(y, H, sy, y0, y1);
+    tap_range(x, W, sx, x0, x1);
+    for (int oy = y0; oy <= y1; ++oy) {
+      const float wy = tap_weight(oy, y, H, sy);
+      if (wy == 0.f) continue;
+      float row[3] = {0.f, 0.f, 0.f};
+      for (int ox = x0; ox <= x1; ++ox) {
+        const float wx = tap_weight(ox, x, W, sx);
+        if (wx == 0.f) continue;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    atomicAdd(&ib[((long)ly.i0 * W + lx.i0) * 3 + c], ly.w0 * lx.w0 * gv[c]);
-    atomicAdd(&ib[((long)ly.i0 * W + lx.i1) * 3 + c], ly.w0 * lx.w1 * gv[c]);
-    atomicAdd(&ib[((long)ly.i1 * W + lx.i0) * 3 + c], ly.w1 * lx.w0 * gv[c]);
-    atomicAdd(&ib[((long)ly.i1 * W + lx.i1) * 3 + c], ly.w1 * lx.w1 * gv[c]);
+        for (int c = 0; c < 3; ++c) row[c] += wx * ob[((long)c * CLIP_RES + oy) * CLIP_RES + ox];
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[c] += wy * row[c];
+    }
   }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) din[(((long)b * H + y) * W + x) * 3 + c] = acc[c] * nm.istd[c];
 }
 
 static Norm3 norm3(const float* mean, const float* stdv) {
@@ -320,14 +346,9 @@ extern "C" int avc_resize_norm_bwd(const float* dout, int B, int H, int W, const
                                    float* dimages, void* stream) {
   if (B <= 0) return 0;
   if (!dout || !dimages || !mean || !stdv || H < 1 || W < 1) { avc_set_error("avc_resize_norm_bwd: bad arguments"); return 1; }
-  if (!(H == CLIP_RES && W == CLIP_RES) &&
-      hipMemsetAsync(dimages, 0, (size_t)B * H * W * 3 * sizeof(float), (hipStream_t)stream) != hipSuccess) {
-    avc_set_error("avc_resize_norm_bwd: memset failed");
-    return 1;
-  }
-  const int n = B * CLIP_RES * CLIP_RES;
-  hipLaunchKernelGGL(resize_norm_bwd_kernel, dim3((n + GLUE_THREADS - 1) / GLUE_THREADS), dim3(GLUE_THREADS), 0, (hipStream_t)stream, dout, dimages,
-                     B, H, W, norm3(mean, stdv));
+  const long n = (long)B * H * W;
+  hipLaunchKernelGGL(resize_norm_bwd_kernel, dim3((unsigned)((n + GLUE_THREADS - 1) / GLUE_THREADS)), dim3(GLUE_THREADS), 0, (hipStream_t)stream, dout,
+                     dimages, B, H, W, norm3(mean, stdv));
   return avc_check_launch("avc_resize_norm_bwd");
 }
 

@@ -38,12 +38,8 @@
 //   AVC_ABL_BWD_RECOMP  NOEH + the price of recomputing h inside the second-order sweep from the staged W_l fragments, priced LOW: a
 //                       second MFMA chain per tile on the same A fragments (one LDS read feeds two MFMAs) + the 16 softplus per lane
 //                       and tile, but NOT the second input array (64 VGPRs) nor the f16 weight set a real version needs
-// and one real variant (parity-valid):
-//   AVC_BWD_KEEP_GBS    turn-around residency: gbar_hs (the last tiles the second-order sweep produces, the first the reverse sweep
-//                       consumes) stays in registers across the turn instead of being re-read (7 tiles); = 2: h_s as well (14 tiles)
-#ifndef AVC_BWD_KEEP_GBS
-#define AVC_BWD_KEEP_GBS 1
-#endif
+// (gbar_hs -- the last tiles the second-order sweep produces, the first the reverse sweep consumes -- ALWAYS stays in registers across
+//  the turn: it has no panel since round 5, see col_sums below; keeping h_s as well spilled 78 registers and lost 5 %)
 template <typename V>
 __device__ __forceinline__ FragPair<V> abl_const_pair() {
   FragPair<V> d;
@@ -84,7 +80,82 @@ struct BwdArgs {
   const char* fpanels;
   char* gpanels;
   const unsigned short* masks;
+  float* colsum;   // [wavefronts of the launch][PanelLayout::CS_FLOATS]: per-wavefront column sums over its points of gbar_hs and gbar_h0
 };
+
+// ---- Column sums over the points.  The second-order term of row 0 of the last SDF layer is dW_last[0, :] += sum_points gbar_u,
+// gbar_u = [gbar_hs ; gbar_h0] / sqrt2: a sum, not a product.  Rounds 2-4 stored gbar_hs and a constant-one tile and let
+// the weight-gradient kernel contract "1 (x) [gbar_hs | gbar_h0]" -- 8 tiles written and 10 read per block for 39 + SKIP numbers.  The
+// values are in this kernel's registers: 32 points on the 32 lanes of a half-wave, so the sum is a lane reduction (transpose_sum below),
+// added to the wavefront's own slot in LDS (single writer, plain read + write: deterministic) and written out once at the end of the
+// launch; the host adds the rows up and scatters them into the dense gradient (packing.Layout.cs_*).  fp32 throughout -- the product
+// had rounded gbar to bf16 first.
+#define AVC_CS_DUMMY 64   // floats behind a slot that take the writes of the non-writing lanes (distinct addresses: no branch, no conflict)
+template <class N> struct ColSum {
+  static constexpr int SLOT_FLOATS = PanelLayout<N>::CS_FLOATS + AVC_CS_DUMMY;
+  static constexpr int LDS_BYTES = BWD_WPB * SLOT_FLOATS * 4;
+};
+typedef AVC_LDS float* cs_slot_t;
+// value of the lane's xor-1 / xor-2 partner (DPP quad permutes: no LDS traffic)
+__device__ __forceinline__ float quad_xor1(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float quad_xor2(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+}
+// Transposing reduction: NV = 8 or 16 values per lane -> ONE per lane, the sum over the half-wave's 32 lanes of value (lane & (NV - 1)).
+// Every butterfly step halves the number of values: of the pair (a, b) the lane keeps the one its own bit selects and gives the other to
+// its partner, who keeps exactly that one -- NV - 1 exchanges instead of NV x 5.  Steps 1, 2 are DPP quad permutes, the others go
+// through the LDS crossbar (ds_bpermute).  (LDS float ATOMICS, the first version of this, cost ~900 cycles per instruction on gfx950:
+// 136 of them per block made the kernel 45 % slower, profiles/r05_ab_kernels.txt.)
+template <int NV>
+__device__ __forceinline__ float transpose_sum(const float (&v)[NV], int lane) {
+  static_assert(NV == 8 || NV == 16, "8 or 16 values per lane");
+  float w[NV / 2];
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+#pragma unroll
+  for (int k = 0; k < NV / 2; ++k) w[k] = (b0 ? v[2 * k + 1] : v[2 * k]) + quad_xor1(b0 ? v[2 * k] : v[2 * k + 1]);
+  float x[NV / 4];
+#pragma unroll
+  for (int k = 0; k < NV / 4; ++k) x[k] = (b1 ? w[2 * k + 1] : w[2 * k]) + quad_xor2(b1 ? w[2 * k] : w[2 * k + 1]);
+  float y[NV / 8];
+#pragma unroll
+  for (int k = 0; k < NV / 8; ++k) y[k] = (b2 ? x[2 * k + 1] : x[2 * k]) + __shfl_xor(b2 ? x[2 * k] : x[2 * k + 1], 4);
+  float z;
+  if constexpr (NV == 16) z = (b3 ? y[1] : y[0]) + __shfl_xor(b3 ? y[0] : y[1], 8);
+  else z = y[0] + __shfl_xor(y[0], 8);
+  return z + __shfl_xor(z, 16);
+}
+// add the block's column sums of NV values per lane to slot[base + (lane & (NV - 1))]: the lanes of the half-wave's first NV lanes
+// write (their half's index is folded into `base` by the caller), every other lane read-modify-writes its own dummy word.  Plain LDS
+// read + write: the slot has a single writer, this wavefront.
+template <class N, int NV>
+__device__ __forceinline__ void col_sums(cs_slot_t slot, int lane, int base, const float (&v)[NV]) {
+#ifdef AVC_ABL_CS_NODPP
+  const float total = v[0];
+#else
+  const float total = transpose_sum<NV>(v, lane);
+#endif
+  const bool writer = (lane & 31) < NV;
+  cs_slot_t dst = writer ? slot + base + (lane & (NV - 1)) : slot + PanelLayout<N>::CS_FLOATS + (lane & 63);
+#ifdef AVC_ABL_CS_NOADD
+  asm volatile("" :: "v"(total), "v"(dst));
+#else
+  *dst = *dst + total;
+#endif
+}
+template <class N>
+__device__ __forceinline__ cs_slot_t cs_init(char* lds_base, int wv, int lane) {
+  cs_slot_t slot = (cs_slot_t)lds_base + wv * ColSum<N>::SLOT_FLOATS;
+  for (int k = lane; k < ColSum<N>::SLOT_FLOATS; k += 64) slot[k] = 0.f;
+  return slot;
+}
+// after the last block: the slot goes to row `row` of the launch's colsum buffer
+template <class N>
+__device__ __forceinline__ void cs_flush(cs_slot_t slot, float* out, long row, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  for (int k = lane; k < PanelLayout<N>::CS_FLOATS; k += 64) out[row * PanelLayout<N>::CS_FLOATS + k] = slot[k];
+}
 
 // The inputs the FIRST MFMA chain and the first epilogues of a block wait for: delta_o (from d_rgb and the forward's colours) and the
 // ReLU masks.  AVC_BWD_PIPE_IN=1: the persistent kernel requests them for its NEXT block under the last layer of the current one
@@ -128,7 +199,7 @@ struct NoRing {
 // role-specialised kernel claims its blocks dynamically and does not know the next one)
 template <class N, bool PIPE = false, class R>
 __device__ __forceinline__ void bwd_sweeps(StageT<BWD_G>& sg, const BwdArgs& a, lds_tab_t Tl, long blk0, long nblk, int lane0,
-                                           int wv, R& ring, BlkIn<N>* bip = nullptr, long blk0_next = 0) {
+                                           int wv, R& ring, cs_slot_t cs, BlkIn<N>* bip = nullptr, long blk0_next = 0) {
   typedef PanelLayout<N> L;
   constexpr AvcOffsets o = Off<N>::value;
   const PointSrc& ps = a.ps;
@@ -204,18 +275,16 @@ __device__ __forceinline__ void bwd_sweeps(StageT<BWD_G>& sg, const BwdArgs& a, 
   }
   const float dsdf = a.d_sdf[i] * vmask;
   const float dsdfS = dsdf * AVC_S;   // OFF_WL0_ACC holds W_last[0,:]/(S sqrt2): undo S for the gradient use
-  {   // operand tiles with one live feature (slot (half 0, j = 0) = feature 0; d_sdf: two): d_sdf and the constant 1 (row 0 of the last layer)
-    b8 fs = zero_frag<b8>(), fo = zero_frag<b8>();
+  {   // operand tile with two live features: d_sdf (row 0 of the last layer), slots (half 0, j = 0, 1)
+    b8 fs = zero_frag<b8>();
     if (h == 0) {   // d_sdf split hi + lo over two slots (both map to row 0, packing.py): 16 bits of mantissa for the one cotangent whose sums cancel heavily
       fs[0] = (__bf16)dsdf;
       fs[1] = (__bf16)(dsdf - (float)fs[0]);
-      fo[0] = (__bf16)vmask;
     }
     tile_store<false>(tiles, L::G_SDF, fs, zero_frag<b8>());
-    tile_store<false>(tiles, L::G_ONE, fo, zero_frag<b8>());
   }
   // ------------------------------------------------------------------ phase E: second-order sweep (i) (bf16)
-  b8 gbs[N::SK];        // gbar_hs: with AVC_BWD_KEEP_GBS it stays in registers for the first layer of the reverse sweep
+  b8 gbs[N::SK];        // gbar_hs: stays in registers for the first layer of the reverse sweep (no panel)
   b8 dfeat[N::HK];      // ybar[1:]: the input of the reverse sweep (written by phase D, read back here)
   auto load_dfeat = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -229,16 +298,25 @@ __device__ __forceinline__ void bwd_sweeps(StageT<BWD_G>& sg, const BwdArgs& a, 
       dfeat[2 * t + 1] = d.a1;
     }
   };
-#if AVC_BWD_KEEP_GBS >= 2
-  h8 hs_keep[N::SK];    // ... and so does h_s
-#endif
   {
     b8 gb0[3];
     {
       PE pe4;
       pe_compute(x, h, pe4);
+      float g0[24];
 #pragma unroll
-      for (int q = 0; q < 24; ++q) gb0[q >> 3][q & 7] = (__bf16)(pe4.d[q] * nbar[q % 3]);
+      for (int q = 0; q < 24; ++q) {
+        g0[q] = pe4.d[q] * nbar[q % 3];
+        gb0[q >> 3][q & 7] = (__bf16)g0[q];
+      }
+      // column sums of gbar_h0 over the block's points: [fragment][half][8 slots] behind the ST gbar_hs tiles of the slot
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = g0[8 * s + j];
+        col_sums<N, 8>(cs, lane, N::ST * 32 + (s * 2 + h) * 8, v);
+      }
     }
     tile_store<false>(tiles, L::G_GB0, gb0[0], gb0[1]);
     tile_store<false>(tiles, L::G_GB0 + 1, gb0[2], zero_frag<b8>());
@@ -248,20 +326,24 @@ __device__ __forceinline__ void bwd_sweeps(StageT<BWD_G>& sg, const BwdArgs& a, 
 #else
 #define AVC_E_LOADH(PH) tile_load<(AVC_BWD_E_NT != 0), h8>(ftiles, (PH) + t)
 #endif
-#define AVC_SECOND_(OUT, PH, PT, KEEPH)                                                                      \
+#define AVC_SECOND(OUT, PH, PT)                                                                              \
   AVC_PRE(return AVC_E_LOADH(PH);),                                                                          \
   AVC_EPID(FragPair<h8>, _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                     \
             OUT[2 * t][j] = (__bf16)(acc[j] * sig_from_h((float)d.a0[j]));                                   \
             OUT[2 * t + 1][j] = (__bf16)(acc[8 + j] * sig_from_h((float)d.a1[j])); }                         \
           pin2(OUT[2 * t], OUT[2 * t + 1]);                                                                  \
-          KEEPH                                                                                              \
           tile_store<true>(tiles, (PT) + t, OUT[2 * t], OUT[2 * t + 1]);)
-#define AVC_SECOND(OUT, PH, PT) AVC_SECOND_(OUT, PH, PT, )
-#if AVC_BWD_KEEP_GBS >= 2
-#define AVC_SECOND_S(OUT, PH, PT) AVC_SECOND_(OUT, PH, PT, hs_keep[2 * t] = d.a0; hs_keep[2 * t + 1] = d.a1;)
-#else
-#define AVC_SECOND_S(OUT, PH, PT) AVC_SECOND_(OUT, PH, PT, )
-#endif
+    // the skip layer's gbar_hs: no panel -- the fragments stay in `gbs`, the column sums over the points go to the wavefront's slot
+#define AVC_SECOND_S(OUT, PH)                                                                                \
+  AVC_PRE(return AVC_E_LOADH(PH);),                                                                          \
+  AVC_EPID(FragPair<h8>, float v[16];                                                                        \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                    \
+            v[j] = acc[j] * sig_from_h((float)d.a0[j]);                                                      \
+            v[8 + j] = acc[8 + j] * sig_from_h((float)d.a1[j]);                                              \
+            OUT[2 * t][j] = (__bf16)v[j];                                                                    \
+            OUT[2 * t + 1][j] = (__bf16)v[8 + j]; }                                                          \
+          pin2(OUT[2 * t], OUT[2 * t + 1]);                                                                  \
+          col_sums<N, 16>(cs, lane, (t * 2 + h) * 16, v);)
     b8 gb1[N::HK];
     layer_sqd<b8, 3, N::HT>(sg, Wb, o.v[OFF_W0G], nxt<N, OFF_WM0>(sg, Wb, o), gb0, AVC_SECOND(gb1, L::P_H1, L::G_GBH1));
     b8 gbm[N::HK];
@@ -270,10 +352,10 @@ __device__ __forceinline__ void bwd_sweeps(StageT<BWD_G>& sg, const BwdArgs& a, 
       b8 gbm1[N::HK];
       layer_sqd<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wb, o), gbm,
                                   AVC_SECOND(gbm1, L::P_HM + N::HT, L::G_GBHM + N::HT));
-      layer_sqd<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WS], nxt<N, OFF_WLT>(sg, Wb, o), gbm1, AVC_SECOND_S(gbs, L::P_HS, L::G_GBHS));
+      layer_sqd<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WS], nxt<N, OFF_WLT>(sg, Wb, o), gbm1, AVC_SECOND_S(gbs, L::P_HS));
     } else {
       layer_sqd<b8, N::HK, N::HT>(sg, Wb, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wb, o), gb1, AVC_SECOND(gbm, L::P_HM, L::G_GBHM));
-      layer_sqd<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WS], nxt<N, OFF_WLT>(sg, Wb, o), gbm, AVC_SECOND_S(gbs, L::P_HS, L::G_GBHS));
+      layer_sqd<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WS], nxt<N, OFF_WLT>(sg, Wb, o), gbm, AVC_SECOND_S(gbs, L::P_HS));
     }
   }
   // ------------------------------------------------------------------ phase F: reverse sweep (ii) (bf16)
@@ -289,22 +371,14 @@ __device__ __forceinline__ void bwd_sweeps(StageT<BWD_G>& sg, const BwdArgs& a, 
   AVC_PRE(PF3 d; { const FragPair<h8> a_ = tile_load<true, h8>(ftiles, (PH) + t); d.h0 = a_.a0; d.h1 = a_.a1; } \
           { const FragPair<b8> a_ = AVC_F_LOADB(PB); d.b0 = a_.a0; d.b1 = a_.a1; } \
           { const FragPair<h8> a_ = tile_load<true, h8>(ftiles, (PG) + t); d.g0 = a_.a0; d.g1 = a_.a1; } return d;)
-  // the same for the first layer of the reverse sweep: gbar_hs (and h_s) straight from the registers of the second-order sweep when kept
-#if AVC_BWD_KEEP_GBS >= 2
-#define AVC_LOAD3_S(PH, PB, PG)                                                                             \
-  AVC_PRE(PF3 d; d.h0 = hs_keep[2 * t]; d.h1 = hs_keep[2 * t + 1]; d.b0 = gbs[2 * t]; d.b1 = gbs[2 * t + 1];  \
-          { const FragPair<h8> a_ = tile_load<true, h8>(ftiles, (PG) + t); d.g0 = a_.a0; d.g1 = a_.a1; } return d;)
-#elif AVC_BWD_KEEP_GBS == 1
-#define AVC_LOAD3_S(PH, PB, PG)                                                                             \
+  // the first layer of the reverse sweep takes gbar_hs from the registers of the second-order sweep (it has no panel)
+#define AVC_LOAD3_S(PH, PG)                                                                                 \
   AVC_PRE(PF3 d; { const FragPair<h8> a_ = tile_load<true, h8>(ftiles, (PH) + t); d.h0 = a_.a0; d.h1 = a_.a1; } \
           d.b0 = gbs[2 * t]; d.b1 = gbs[2 * t + 1];                                                          \
           { const FragPair<h8> a_ = tile_load<true, h8>(ftiles, (PG) + t); d.g0 = a_.a0; d.g1 = a_.a1; } return d;)
-#else
-#define AVC_LOAD3_S(PH, PB, PG) AVC_LOAD3(PH, PB, PG)
-#endif
     // ubar[:SKIP]/sqrt2 = (W_last[1:,:]^T dfeat + W_last[0,:] d_sdf)/sqrt2 ; 1/sqrt2 is folded into both packs
     layer_sq<b8, N::HK, N::ST>(sg, Wb, o.v[OFF_WLT], nxt<N, OFF_WST>(sg, Wb, o), dfeat,
-      AVC_LOAD3_S(L::P_HS, L::G_GBHS, L::P_GAS), AVC_EPID(PF3,
+      AVC_LOAD3_S(L::P_HS, L::P_GAS), AVC_EPID(PF3,
       float wa[16];
       load16(T + o.v[OFF_WL0_ACC], t, h, wa);
       _Pragma("unroll") for (int j = 0; j < 8; ++j) {
@@ -351,7 +425,6 @@ __device__ __forceinline__ void bwd_sweeps(StageT<BWD_G>& sg, const BwdArgs& a, 
 #undef AVC_LOAD3_S
 #undef AVC_F_LOADB
 #undef AVC_E_LOADH
-#undef AVC_SECOND_
 #undef AVC_SECOND_S
 #undef AVC_F_LASTHOOK
 #undef AVC_REVERSE

@@ -296,6 +296,7 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_ring_kernel(BwdArgs a, R
   ST sg = stage_init<BWD_G>(lds);
   stage_issue(sg, nxt<N, OFF_CHT>(sg, a.Wb0, o), 0);
   const lds_tab_t Tl = tab_to_lds(lds + ST::LDS_BYTES, a.T0, o.v[OFF_TAB_END]);
+  const cs_slot_t cs = cs_init<N>(lds + ST::LDS_BYTES + AVC_TAB_LDS_BYTES, wv, lane0);   // column sums of gbar_hs / gbar_h0 (csrc/avc_bwd_body.h)
   __syncthreads();   // (also: every wavefront has read the role ticket)
   if (threadIdx.x == 0) {
     add_agent(xcd_line(rp, xcd, 1), 1u);             // started -- BEFORE the first claim (the consumers' termination test relies on it)
@@ -309,12 +310,13 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_ring_kernel(BwdArgs a, R
     // the next group is claimed under this one (the returning atomic costs ~1 us); slot (it + 1) & 1 was last read before the
     // barrier that ended iteration it - 1
     if (threadIdx.x == 0) s_w[4 + ((it + 1) & 1)] = add_agent(rp.ctl + RC_NEXT, 1u);
-    bwd_sweeps<N>(sg, a, Tl, (long)g * BWD_WPB, nblk, lane0, wv, ring);
+    bwd_sweeps<N>(sg, a, Tl, (long)g * BWD_WPB, nblk, lane0, wv, ring, cs);
     ++groups;
     __syncthreads();
     g = s_w[4 + ((it + 1) & 1)];
     if (s_w[1]) break;
   }
+  cs_flush<N>(cs, a.colsum, (long)blockIdx.x * BWD_WPB + wv, lane0);   // (rows of consumer workgroups stay as the caller zeroed them)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my arrivals are performed
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -334,10 +336,10 @@ extern "C" int avc_render_points_bwd_ring(int net, const float* pts, const float
                                           int S, int ldz, float sample_dist, long npts, const void* wbf16, const float* tab,
                                           const int* offs, const float* d_sdf, const float* d_normal, const float* d_rgb,
                                           const float* rgb_fwd, const void* fpanels, void* gpanels, const void* masks,
-                                          void* ctl, void* ring, float* partial, float* bias_partial, const int* pb_tiles, int ntypes,
-                                          int cpt, int nslots, int grid, void* stream) {
+                                          float* colsum, void* ctl, void* ring, float* partial, float* bias_partial, const int* pb_tiles,
+                                          int ntypes, int cpt, int nslots, int grid, void* stream) {
   if (npts <= 0) return 0;
-  if (!fpanels || !gpanels || !masks || !rgb_fwd || !ctl || !ring || !partial || !bias_partial || !pb_tiles) {
+  if (!fpanels || !gpanels || !masks || !rgb_fwd || !colsum || !ctl || !ring || !partial || !bias_partial || !pb_tiles) {
     avc_set_error("avc_render_points_bwd_ring: NULL buffer");
     return 1;
   }
@@ -359,7 +361,7 @@ extern "C" int avc_render_points_bwd_ring(int net, const float* pts, const float
   for (int t = 0; t < RING_NTY_MAX; ++t) rp.pb[t] = t < ntypes ? pb_tiles[t] : 0;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(ctl, 0, (size_t)RC_WORDS * 4, s) != hipSuccess) { avc_set_error("avc_render_points_bwd_ring: memset failed"); return 1; }
-  const int prod_lds = StageT<BWD_G>::LDS_BYTES + AVC_TAB_LDS_BYTES, cons_lds = WG_DEPTH * WG_BUF_BYTES;
+  const int prod_lds = StageT<BWD_G>::LDS_BYTES + AVC_TAB_LDS_BYTES + ColSum<NetFull>::LDS_BYTES, cons_lds = WG_DEPTH * WG_BUF_BYTES;
   const int lds_bytes = prod_lds > cons_lds ? prod_lds : cons_lds;
   static unsigned long long attr_seen = 0;
   if (avc_first_use_on_device(attr_seen)) {
@@ -367,7 +369,7 @@ extern "C" int avc_render_points_bwd_ring(int net, const float* pts, const float
     (void)hipFuncSetAttribute((const void*)mlp_bwd_ring_kernel<NetSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   }
   const BwdArgs args{ps, npts, (const b8*)wbf16, tab, d_sdf, d_normal, d_rgb, rgb_fwd, (const char*)fpanels, (char*)gpanels,
-                     (const unsigned short*)masks};
+                     (const unsigned short*)masks, colsum};
   if (net == AVC_NET_FULL)
     hipLaunchKernelGGL((mlp_bwd_ring_kernel<NetFull>), dim3(grid), dim3(64 * BWD_WPB), lds_bytes, s, args, rp);
   else if (net == AVC_NET_SMALL)

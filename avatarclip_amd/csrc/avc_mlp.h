@@ -443,22 +443,24 @@ struct PanelLayout {
   static constexpr int P_R1 = P_XN + 1;             // r1 (HT)
   static constexpr int P_R2 = P_R1 + HT;            // r2 (HT, only NC==1)
   static constexpr int P_TILES = P_R2 + NC * HT;    // tiles per block of the F region
-  // ---- G region.  (gbar_hs, gbar_h0) and (ybar[1:], d_sdf) are adjacent for the same reason
+  // ---- G region.  (ybar[1:], d_sdf) are adjacent for the same reason.  gbar_hs has NO panel: its only consumers are the first layer of
+  // the reverse sweep (which takes it from the registers of the second-order sweep) and the column sum over the points that is the
+  // second-order term of row 0 of the last layer (reduced in the backward kernel: col_sums in csrc/avc_bwd_body.h) -- rounds 2-4 wrote it,
+  // and a constant-one tile, for a "1 (x) [gbar_hs | gbar_h0]" product in the weight-gradient kernel: 8 tiles written + 10 read per block
   static constexpr int G_GBH1 = 0;                  // gbar_h1
   static constexpr int G_GBHM = G_GBH1 + HT;        // gbar_hm[NM]
-  static constexpr int G_GBHS = G_GBHM + NM * HT;   // gbar_hs (ST)
-  static constexpr int G_GB0 = G_GBHS + ST;         // gbar_h0 (2)
+  static constexpr int G_GB0 = G_GBHM + NM * HT;    // gbar_h0 (2)
   static constexpr int G_AB1 = G_GB0 + 2;           // abar_1
   static constexpr int G_ABM = G_AB1 + HT;          // abar_m[NM]
   static constexpr int G_ABS = G_ABM + NM * HT;     // abar_s (ST)
   static constexpr int G_DFEAT = G_ABS + ST;        // ybar[1:] (HT)
   static constexpr int G_SDF = G_DFEAT + HT;        // feature 0 = d_sdf (1)
-  static constexpr int G_ONE = G_SDF + 1;           // feature 0 = 1 (1)
-  static constexpr int G_D1 = G_ONE + 1;            // delta1 (HT)
+  static constexpr int G_D1 = G_SDF + 1;            // delta1 (HT)
   static constexpr int G_D2 = G_D1 + HT;            // delta2 (HT, only NC==1)
   static constexpr int G_DO = G_D2 + NC * HT;       // delta_o (1)
   static constexpr int G_TILES = G_DO + 1;          // tiles per block of the G region
   static constexpr int MASK_U16 = 2 * HT * 64;      // ReLU masks of r1 / r2 per 32-point block: [layer][tile][lane] x 16 bits
+  static constexpr int CS_FLOATS = ST * 32 + 48;    // column sums per wavefront: [ST][2 halves][16 acc registers] of gbar_hs, [3 frags][2][8 slots] of gbar_h0
 };
 // the no-grad forward parks only what its own normal sweep reads back (h1, hm, feature), in a per-wavefront slot it reuses
 template <class N>

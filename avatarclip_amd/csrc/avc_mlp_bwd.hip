@@ -29,6 +29,7 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(BwdArgs a) {
   stage_issue(sg, nxt<N, OFF_CHT>(sg, a.Wb0, o), 0);
   // the fp32 table lives in LDS: a global load in an epilogue would queue behind the LDS-DMA of the next weight group
   const lds_tab_t Tl = tab_to_lds(lds + ST::LDS_BYTES, a.T0, o.v[OFF_TAB_END]);
+  const cs_slot_t cs = cs_init<N>(lds + ST::LDS_BYTES + AVC_TAB_LDS_BYTES, wv, lane0);   // this wavefront's column-sum slot (csrc/avc_bwd_body.h)
   __syncthreads();
   NoRing ring;
   // every wavefront of a workgroup runs the same number of iterations (workgroup-uniform loop bound)
@@ -36,20 +37,32 @@ __global__ __launch_bounds__(64 * BWD_WPB) void mlp_bwd_kernel(BwdArgs a) {
   BlkIn<N> bi;     // the block's first inputs, requested one block ahead (csrc/avc_bwd_body.h)
   load_blk_in<N>(a, (long)blockIdx.x * BWD_WPB + wv, nblk, lane0, bi);
   for (long blk0 = (long)blockIdx.x * BWD_WPB; blk0 < nblk; blk0 += (long)gridDim.x * BWD_WPB)
-    bwd_sweeps<N, true>(sg, a, Tl, blk0, nblk, lane0, wv, ring, &bi, blk0 + (long)gridDim.x * BWD_WPB);
+    bwd_sweeps<N, true>(sg, a, Tl, blk0, nblk, lane0, wv, ring, cs, &bi, blk0 + (long)gridDim.x * BWD_WPB);
 #else
   for (long blk0 = (long)blockIdx.x * BWD_WPB; blk0 < nblk; blk0 += (long)gridDim.x * BWD_WPB)
-    bwd_sweeps<N>(sg, a, Tl, blk0, nblk, lane0, wv, ring);
+    bwd_sweeps<N>(sg, a, Tl, blk0, nblk, lane0, wv, ring, cs);
 #endif
+  cs_flush<N>(cs, a.colsum, (long)blockIdx.x * BWD_WPB + wv, lane0);
+}
+
+// rows x floats of the colsum buffer a launch with `max_waves` fills: one row per wavefront of the (persistent) grid
+extern "C" int avc_bwd_colsum_floats(int net) { return net == AVC_NET_FULL ? PanelLayout<NetFull>::CS_FLOATS : PanelLayout<NetSmall>::CS_FLOATS; }
+extern "C" long avc_bwd_colsum_rows(long npts, long max_waves) {
+  const long nblk = (npts + 31) / 32;
+  long ngroups = (nblk + BWD_WPB - 1) / BWD_WPB, maxg = max_waves / BWD_WPB;
+  if (maxg < 1) maxg = 1;
+  long grid = ngroups < maxg ? ngroups : maxg;
+  if (grid < 1) grid = 1;
+  return grid * BWD_WPB;
 }
 
 extern "C" int avc_render_points_bwd(int net, const float* pts, const float* rays_o, const float* rays_d, const float* z,
                                      int S, int ldz, float sample_dist, long npts, const void* wbf16, const float* tab,
                                      const int* offs, const float* d_sdf, const float* d_normal, const float* d_rgb,
-                                     const float* rgb_fwd, const void* fpanels, void* gpanels, const void* masks, long max_waves,
-                                     void* stream) {
+                                     const float* rgb_fwd, const void* fpanels, void* gpanels, const void* masks, float* colsum,
+                                     long max_waves, void* stream) {
   if (npts <= 0) return 0;
-  if (!fpanels || !gpanels || !masks || !rgb_fwd) { avc_set_error("avc_render_points_bwd: fpanels / gpanels / masks / rgb_fwd == NULL"); return 1; }
+  if (!fpanels || !gpanels || !masks || !rgb_fwd || !colsum) { avc_set_error("avc_render_points_bwd: fpanels / gpanels / masks / rgb_fwd / colsum == NULL"); return 1; }
   if (!(net == AVC_NET_FULL ? offsets_match<NetFull>(offs) : offsets_match<NetSmall>(offs))) {
     avc_set_error("packed-blob offsets differ from the compiled-in table (regenerate csrc/avc_offsets_gen.h)");
     return 1;
@@ -62,7 +75,7 @@ extern "C" int avc_render_points_bwd(int net, const float* pts, const float* ray
   int grid = (int)(ngroups < maxg ? ngroups : maxg);
   if (grid < 1) grid = 1;
   hipStream_t s = (hipStream_t)stream;
-  const int lds_bytes = StageT<BWD_G>::LDS_BYTES + AVC_TAB_LDS_BYTES;
+  const int lds_bytes = StageT<BWD_G>::LDS_BYTES + AVC_TAB_LDS_BYTES + ColSum<NetFull>::LDS_BYTES;
   if (offs[OFF_TAB_END] * 4 > AVC_TAB_LDS_BYTES) { avc_set_error("fp32 table does not fit its LDS window"); return 1; }
   static unsigned long long attr_seen = 0;
   if (avc_first_use_on_device(attr_seen)) {
@@ -70,7 +83,7 @@ extern "C" int avc_render_points_bwd(int net, const float* pts, const float* ray
     (void)hipFuncSetAttribute((const void*)mlp_bwd_kernel<NetSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   }
   const BwdArgs args{ps, npts, (const b8*)wbf16, tab, d_sdf, d_normal, d_rgb, rgb_fwd, (const char*)fpanels, (char*)gpanels,
-                     (const unsigned short*)masks};
+                     (const unsigned short*)masks, colsum};
   if (net == AVC_NET_FULL)
     hipLaunchKernelGGL((mlp_bwd_kernel<NetFull>), dim3(grid), dim3(64 * BWD_WPB), lds_bytes, s, args);
   else if (net == AVC_NET_SMALL)

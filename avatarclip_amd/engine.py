@@ -39,6 +39,9 @@ class _DevLayout:
         off = np.zeros(lay.nparam + 1, np.int64)
         np.cumsum(np.bincount(tgt, minlength=lay.nparam), out=off[1:])
         self.csr_off, self.csr_src, self.csr_scale = t(off.astype(np.int32)), t(src[order].astype(np.int32)), t(scl[order])
+        # column sums of gbar_hs / gbar_h0 (second-order term of row 0 of the last SDF layer, reduced inside the backward kernel) -> the
+        # dense gradient: every target parameter exactly once
+        self.cs_src, self.cs_tgt, self.cs_scale = t(lay.cs_src), t(lay.cs_tgt), t(lay.cs_scale)
         self._offsets_arr = (ctypes.c_int * PK.OFF_COUNT)(*[int(v) for v in lay.offsets])
         self.offsets = ctypes.cast(self._offsets_arr, ctypes.c_void_p)
 
@@ -240,6 +243,8 @@ class Engine:
         self.grad_tiles = self.lib.avc_grad_panel_tiles(self.net)
         assert (self.fwd_tiles, self.grad_tiles) == (self.dl.lay.panel["FTILES"], self.dl.lay.panel["GTILES"]), \
             "panel layout mismatch between packing.py and csrc/avc_mlp.h"
+        assert self.lib.avc_bwd_colsum_floats(self.net) == self.dl.lay.cs_size, "column-sum layout mismatch between packing.py and csrc/avc_mlp.h"
+        self._colsum = None           # [wavefronts of a backward launch][cs_size]: the backward kernel's per-wavefront column sums
         self.mask_u16 = self.lib.avc_mask_u16_per_block(self.net)
         self.fwd_scr_bytes = self.lib.avc_fwd_scratch_bytes_per_wave(self.net)
         self._fwd_scratch = None
@@ -517,6 +522,10 @@ class Engine:
         if rg is not None:
             rg["err"].zero_()
         pairs_host = rg["rest"] if rg is not None else self._pairs_host
+        cs_rows = int(self.lib.avc_bwd_colsum_rows(min(R, rays_per_slab) * S, self.MAX_BWD_WAVES)) if rg is None else 8 * rg["grid"]
+        if self._colsum is None or self._colsum.shape[0] < cs_rows:
+            self._colsum = torch.zeros(cs_rows, lay.cs_size, device=self.device, dtype=torch.float32)
+        cs_total = None               # sum over wavefronts and slabs of the column sums
         for c0 in range(0, R, rays_per_chunk):
             c1 = min(R, c0 + rays_per_chunk)
             if not panels_valid:
@@ -537,11 +546,14 @@ class Engine:
                 bwd_args = (self.net, None, rays_o.data_ptr() + s0 * 3 * esz, rays_d.data_ptr() + s0 * 3 * esz,
                             z.data_ptr() + s0 * z.stride(0) * esz, S, z.stride(0), float(sample_dist), npts, L.ptr(pk.w_bf16), L.ptr(pk.tab),
                             self.dl.offsets, d_sdf.data_ptr() + s0 * S * esz, d_n.data_ptr() + s0 * S * 3 * esz,
-                            d_rgb.data_ptr() + s0 * S * 6 * esz, rgb.data_ptr() + s0 * S * 6 * esz, fptr, L.ptr(gpanels), mptr)
+                            d_rgb.data_ptr() + s0 * S * 6 * esz, rgb.data_ptr() + s0 * S * 6 * esz, fptr, L.ptr(gpanels), mptr, L.ptr(self._colsum))
                 if rg is None:
+                    rows = int(self.lib.avc_bwd_colsum_rows(npts, self.MAX_BWD_WAVES))     # every row of the launch's grid is written
                     with Engine._Timed("avc_render_points_bwd", npts):
                         L.check(self.lib.avc_render_points_bwd(*bwd_args, self.MAX_BWD_WAVES, st), "avc_render_points_bwd")
                 else:
+                    rows = 8 * rg["grid"]
+                    self._colsum[:rows].zero_()          # consumer workgroups write no row
                     rg["partial"].zero_()
                     rg["bias"].zero_()
                     with Engine._Timed("avc_render_points_bwd_ring", npts):
@@ -555,6 +567,8 @@ class Engine:
                         if int(rg["ctl"][64]) != 0:
                             raise RuntimeError("avc_render_points_bwd_ring: %d spin time-out(s), first site %d, counters %s"
                                                % (int(rg["ctl"][64]), int(rg["ctl"][65]), self.ring_stats))
+                cs_slab = self._colsum[:rows].sum(0)      # (torch's reduction: a fixed tree, deterministic)
+                cs_total = cs_slab if cs_total is None else cs_total + cs_slab
                 ns = max(1, min(self.WG_MAX_SPLITS, nblk // self.WG_BLOCKS_PER_SPLIT, nblk))
                 with Engine._Timed("avc_weight_grad(all pairs)", npts):
                     L.check(self.lib.avc_weight_grad_all(fptr, self.fwd_tiles, L.ptr(gpanels), self.grad_tiles, len(pairs_host),
@@ -587,6 +601,8 @@ class Engine:
             grad.index_add_(0, self.dl.un_tgt, gout[self.dl.un_src] * self.dl.un_scale)
             if lay.gbias_size:
                 grad.index_add_(0, self.dl.ub_tgt, gbias[self.dl.ub_src])
+        if cs_total is not None:      # second-order term of row 0 of the last SDF layer: sum_points [gbar_hs ; gbar_h0] / sqrt2 (unique targets)
+            grad.index_add_(0, self.dl.cs_tgt, cs_total[self.dl.cs_src] * self.dl.cs_scale)
         # (d loss / d (sdf bias) = sum of d_sdf over all points cancels heavily -- the eikonal term pulls both ways -- and a single bf16
         # slot of d_sdf used to get it wrong by several percent; the tile now carries d_sdf as hi + lo, see packing.py / avc_bwd_body.h.
         # AVC_SDF_BIAS_FP32=1 restores the old override from the fp32 tensor for A/B.)

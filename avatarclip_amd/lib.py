@@ -27,7 +27,9 @@ _SIGS = {
     "avc_fwd_panel_tiles": (c_int, [c_int]),
     "avc_grad_panel_tiles": (c_int, [c_int]),
     "avc_mask_u16_per_block": (c_int, [c_int]),
-    "avc_render_points_bwd": (c_int, [c_int, P, P, P, P, c_int, c_int, c_float, c_long, P, P, P, P, P, P, P, P, P, P, c_long, P]),
+    "avc_render_points_bwd": (c_int, [c_int, P, P, P, P, c_int, c_int, c_float, c_long, P, P, P, P, P, P, P, P, P, P, P, c_long, P]),
+    "avc_bwd_colsum_floats": (c_int, [c_int]),
+    "avc_bwd_colsum_rows": (c_long, [c_long, c_long]),
     "avc_mc_classify": (c_int, [P, c_int, c_int, c_int, c_float, P, P, P, P]),
     "avc_mc_emit": (c_int, [P, c_int, c_int, c_int, c_float, P, P, P, P, P, P, P, P, P]),
     "avc_text_attention_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
@@ -73,7 +75,7 @@ _RING_SIGS = {
     "avc_bwd_ring_ctl_bytes": (c_long, []),
     "avc_bwd_ring_payload_bytes": (c_long, [c_int, c_int, c_int]),
     "avc_bwd_ring_types": (c_int, [c_int]),
-    "avc_render_points_bwd_ring": (c_int, [c_int, P, P, P, P, c_int, c_int, c_float, c_long, P, P, P, P, P, P, P, P, P, P,
+    "avc_render_points_bwd_ring": (c_int, [c_int, P, P, P, P, c_int, c_int, c_float, c_long, P, P, P, P, P, P, P, P, P, P, P,
                                            P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
 }
 

@@ -186,6 +186,13 @@ class Layout:
     un_scale: np.ndarray
     ub_src: np.ndarray
     ub_tgt: np.ndarray
+    # the second-order term of row 0 of the last SDF layer, dW_last[0, :] += sum_points gbar_u, is a COLUMN SUM over the
+    # points of gbar_hs and gbar_h0 -- not a product.  The backward kernel reduces it itself (csrc/avc_bwd_body.h: col_sums) and leaves, per
+    # wavefront, cs_size floats: [ST tiles][2 halves][16 accumulator registers] of gbar_hs, then [3 fragments][2 halves][8 slots] of gbar_h0.
+    cs_size: int = 0
+    cs_src: np.ndarray = None     # index into that vector ...
+    cs_tgt: np.ndarray = None     # ... flat parameter index (row 0 of the last SDF layer) ...
+    cs_scale: np.ndarray = None   # ... and factor
 
 
 def _elem(pbase, name, shape, row, col, transposed):
@@ -330,8 +337,10 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
     c = 0
     F_ORDER = [("H1", HT), ("HM", NMID * HT), ("HS", ST), ("H0", 2), ("GA1", HT), ("GAM", NMID * HT), ("GAS", ST), ("FEAT", HT),
                ("XN", 1), ("R1", HT), ("R2", NCMID * HT)]
-    G_ORDER = [("GBH1", HT), ("GBHM", NMID * HT), ("GBHS", ST), ("GB0", 2), ("AB1", HT), ("ABM", NMID * HT), ("ABS", ST),
-               ("DFEAT", HT), ("SDF", 1), ("ONE", 1), ("D1", HT), ("D2", NCMID * HT), ("DO", 1)]
+    # (no gbar_hs panel and no constant-one panel since round 5: their only consumer was the product "1 (x) [gbar_hs | gbar_h0]" = a column
+    # sum over the points, which the backward kernel now takes from its registers: 8 tiles less written, 10 tile reads less per block)
+    G_ORDER = [("GBH1", HT), ("GBHM", NMID * HT), ("GB0", 2), ("AB1", HT), ("ABM", NMID * HT), ("ABS", ST),
+               ("DFEAT", HT), ("SDF", 1), ("D1", HT), ("D2", NCMID * HT), ("DO", 1)]
     tile_type = []
     for region, order in ((0, F_ORDER), (1, G_ORDER)):
         for name, nt in order:
@@ -422,8 +431,8 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
     # cancellation: the eikonal term pulls both ways) come out of the same product as every other row, without a special case
     r0s = lambda f: 0 if f in (0, 1) else -1
     assert frag_feature(0, 0, 0) == 0 and frag_feature(0, 0, 1) == 1
-    # (its input [hs | pe] = the adjacent panels HS, H0 resp. GBHS, GB0: one product over ST + 2 column tiles each)
-    assert P["H0"] == P["HS"] + ST and P["GB0"] == P["GBHS"] + ST
+    # (its input [hs | pe] = the adjacent panels HS, H0: one product over ST + 2 column tiles)
+    assert P["H0"] == P["HS"] + ST
 
     def last_cols(lo_as_x):
         a, b = feat_std(SKIP), feat_pe(lo_as_x, shift=SKIP)
@@ -433,7 +442,22 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
     assert P["SDF"] == P["DFEAT"] + HT
     rows_last = lambda f: r1(f) if f < 32 * HT else r0s(f - 32 * HT)
     add_pair(P["DFEAT"], HT + 1, P["HS"], ST + 2, ll, rows_last, last_cols(True), scale=hs_scale, bname=bl)
-    add_pair(P["ONE"], 1, P["GBHS"], ST + 2, ll, r0, last_cols(False), scale=1 / SQ2)
+    # second-order term of row 0: sum_points [gbar_hs | gbar_h0] / sqrt2, reduced inside the backward kernel (Layout.cs_*)
+    cs_src, cs_tgt = [], []
+    for t in range(ST):
+        for h in range(2):
+            for r in range(16):
+                f = 32 * t + acc_row(r, h)
+                if f < SKIP:
+                    cs_src.append((t * 2 + h) * 16 + r)
+                    cs_tgt.append(pbase[ll] + f)
+    for q in range(24):
+        for h in range(2):
+            f = pe_feat(h, q, False)
+            if f >= 0:
+                cs_src.append(ST * 32 + ((q >> 3) * 2 + h) * 8 + (q & 7))
+                cs_tgt.append(pbase[ll] + SKIP + f)
+    assert len(set(cs_tgt)) == len(cs_tgt) == SKIP + 39, "every column of row 0 exactly once"
     # colour
     fx = feat_xn()
     c0col = lambda f: (6 + f) if f < H else fx(f - H)
@@ -449,7 +473,9 @@ def build_layout(H: int, NMID: int, NCMID: int) -> Layout:
                   idx32=np.concatenate(idx32), scale32=np.concatenate(sc32), offsets=offsets, panel=P, pairs=pairs,
                   gout_size=gout[0], gbias_size=gbias[0],
                   un_src=np.concatenate(un_src), un_tgt=np.concatenate(un_tgt), un_scale=np.concatenate(un_scale),
-                  ub_src=np.asarray(ub_src, np.int64), ub_tgt=np.asarray(ub_tgt, np.int64))
+                  ub_src=np.asarray(ub_src, np.int64), ub_tgt=np.asarray(ub_tgt, np.int64),
+                  cs_size=ST * 32 + 48, cs_src=np.asarray(cs_src, np.int64), cs_tgt=np.asarray(cs_tgt, np.int64),
+                  cs_scale=np.full(len(cs_src), 1 / SQ2, np.float32))
 
 
 def layout_for(spec: NetSpec) -> Layout:

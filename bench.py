@@ -34,7 +34,7 @@ TILE = 64            # bytes per point of one 32-feature operand tile (2 KiB per
 # these kernels is a chain of dense contractions), so `frac` is ALWAYS algorithmic FLOPs / time / 2.5 PFLOP/s; what actually
 # limits a kernel of this design is reported beside it (`limited_by`, `hbm_frac_counter` = PMC bytes / time / 8 TB/s,
 # `traffic_ratio` = PMC bytes / algorithmic bytes).  Algorithmic bytes per point = the operand tiles a kernel must read once and
-# write once (full nets: 180 tiles = 11.25 KiB per point in total: 89 written by the forward kernel, 91 by the backward kernel).
+# write once (full nets: 172 tiles = 10.75 KiB per point in total: 89 written by the forward kernel, 83 by the backward kernel).
 KERNEL_ROOFLINES = {
     "avc_sdf_forward": dict(kernel="mlp_sdf_kernel", limited_by="engine (MFMA + VALU + LDS issue of the register-resident MLP)", flop_per_point=F_SDF_ONLY,
                             bytes_per_point=4 + 4 + 1,
@@ -43,13 +43,13 @@ KERNEL_ROOFLINES = {
     "avc_render_points_fwd_train": dict(kernel="mlp_render_kernel<train>", limited_by="engine, with the forward-type tile stores riding along", flop_per_point=F_PT,
                                         bytes_per_point=89 * TILE + 76,
                                         note="differentiable forward (F_pt = 1 186 816 FLOP/point) + the 89 forward-type operand tiles"),
-    "avc_render_points_bwd": dict(kernel="mlp_bwd_kernel", limited_by="hbm", flop_per_point=F_PT, bytes_per_point=(91 + 62) * TILE + 80,
-                                  note="colour backward + second-order + reverse sweep (F_pt FLOP/point, no forward recompute): writes 91 "
-                                       "gradient-type tiles, reads h and g_a (62 tiles); its own gbar_h / ybar / second h re-reads (70 tiles) are on "
+    "avc_render_points_bwd": dict(kernel="mlp_bwd_kernel", limited_by="hbm", flop_per_point=F_PT, bytes_per_point=(83 + 62) * TILE + 80,
+                                  note="colour backward + second-order + reverse sweep (F_pt FLOP/point, no forward recompute): writes 83 "
+                                       "gradient-type tiles, reads h and g_a (62 tiles); its own gbar_h / ybar / second h re-reads (63 tiles) are on "
                                        "top of the algorithmic bytes"),
-    "avc_weight_grad(all pairs)": dict(kernel="weight_grad_all_kernel", limited_by="hbm", flop_per_point=F_PT, bytes_per_point=180 * TILE,
+    "avc_weight_grad(all pairs)": dict(kernel="weight_grad_all_kernel", limited_by="hbm", flop_per_point=F_PT, bytes_per_point=172 * TILE,
                                        note="dW = sum_points A^T B from the operand panels (F_pt FLOP/point): every tile is used by ONE product "
-                                            "pair, so operands streamed from HBM cap the kernel at AI = 103 FLOP/B, below the 312 FLOP/B ridge"),
+                                            "pair, so operands streamed from HBM cap the kernel at AI = 108 FLOP/B, below the 312 FLOP/B ridge"),
 }
 
 

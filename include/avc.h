@@ -110,12 +110,19 @@ int avc_render_points_fwd_train(int net, const float* pts, const float* rays_o, 
  * the colour backward, the second-order sweep and the reverse sweep (bf16 operands) and writes the gradient-type operand
  * tiles of the slab to gpanels ((nblk + 1) blocks of avc_grad_panel_tiles(net) tiles, block 0 = the slab's first block);
  * avc_weight_grad_all then contracts both regions over the slab's points.  max_waves bounds the resident grid (persistent
- * workgroups of 8 wavefronts). */
+ * workgroups of 8 wavefronts).
+ * One term of the weight gradient is not a product and does not go through the panels: the second-order term of row 0 of the last
+ * SDF layer, dW_last[0, :] += sum_points [gbar_hs ; gbar_h0] / sqrt2 (fields.py:96-107 under main.py:537).  The kernel
+ * reduces it over each wavefront's points and writes colsum[avc_bwd_colsum_rows(npts, max_waves)][avc_bwd_colsum_floats(net)]: per row
+ * [ST tiles][2 halves][16 accumulator registers] of gbar_hs, then [3 fragments][2 halves][8 slots] of gbar_h0; the caller adds the rows
+ * (and the slabs) up and scatters them into the dense gradient (packing.Layout.cs_src / cs_tgt / cs_scale). */
+int avc_bwd_colsum_floats(int net);
+long avc_bwd_colsum_rows(long npts, long max_waves);
 int avc_render_points_bwd(int net, const float* pts, const float* rays_o, const float* rays_d, const float* z,
                           int S, int ldz, float sample_dist, long npts, const void* wbf16, const float* tab,
                           const int* offs /* host */, const float* d_sdf, const float* d_normal, const float* d_rgb,
-                          const float* rgb_fwd, const void* fpanels, void* gpanels, const void* masks, long max_waves,
-                          void* stream);
+                          const float* rgb_fwd, const void* fpanels, void* gpanels, const void* masks, float* colsum,
+                          long max_waves, void* stream);
 
 /* Every weight-gradient product of one slab in one launch.  pairs (host) = npairs x {pa, ta, pb, tb, out_off, bias_off,
  * type_a, type_b}: pair i contracts A tiles pa .. pa+ta-1 with B tiles pb .. pb+tb-1 (1 <= ta <= 8, 1 <= tb <= 9, or the merged

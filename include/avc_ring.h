@@ -31,7 +31,8 @@ int avc_bwd_ring_types(int net);
 int avc_render_points_bwd_ring(int net, const float* pts, const float* rays_o, const float* rays_d, const float* z,
                                int S, int ldz, float sample_dist, long npts, const void* wbf16, const float* tab,
                                const int* offs /* host */, const float* d_sdf, const float* d_normal, const float* d_rgb,
-                               const float* rgb_fwd, const void* fpanels, void* gpanels, const void* masks, void* ctl,
+                               const float* rgb_fwd, const void* fpanels, void* gpanels, const void* masks,
+                               float* colsum /* [8 grid][avc_bwd_colsum_floats(net)], zeroed by the caller */, void* ctl,
                                void* ring, float* partial, float* bias_partial, const int* pb_tiles /* host */, int ntypes,
                                int cpt, int nslots, int grid, void* stream);
 

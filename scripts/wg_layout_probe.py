@@ -1,5 +1,5 @@
 """weight-gradient kernel per pair shape (development aid): each (ta, tb, type_a, type_b) of the real pair list alone over 4 Mi
-points of panels with the real region strides (F region 89 tiles, G region 91 tiles per block): python scripts/wg_layout_probe.py"""
+points of panels with the real region strides (F region 89 tiles, G region 83 tiles per block): python scripts/wg_layout_probe.py"""
 import sys, os, ctypes, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from avatarclip_amd import lib as L
@@ -8,7 +8,7 @@ dev = torch.device("cuda")
 nblk = 1 << 17     # 4 Mi points
 st = torch.cuda.current_stream().cuda_stream
 nsplit = 256
-ftiles, gtiles = 89, 91
+ftiles, gtiles = 89, 83
 fpanels = torch.zeros(nblk * ftiles * 1024, dtype=torch.int16, device=dev)
 gpanels = torch.zeros(nblk * gtiles * 1024, dtype=torch.int16, device=dev)
 out = torch.empty(nsplit, 4 * 72 * 1024, device=dev)

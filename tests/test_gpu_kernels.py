@@ -336,7 +336,7 @@ def test_head_fusions_equal_their_torch_statements(monkeypatch):
         monkeypatch.setattr(E, "FUSED_PACK", False)
         b = E.Packed(dl, flat)
         assert torch.equal(a.w_f16, b.w_f16) and torch.equal(a.w_bf16, b.w_bf16) and torch.equal(a.tab, b.tab)
-    from tests.test_gpu_ring import _nets
+    from tests.ring_cases import _nets
     ren = _nets(True, dev)
     g = torch.Generator().manual_seed(2)
     R = 777

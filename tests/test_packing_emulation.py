@@ -61,7 +61,8 @@ def test_emulated_wave_matches_analytic(name, spec):
         assert np.allclose(rgb, f["rgb6"][sl].numpy(), atol=1e-9)
         blocks.append(panels)
     gout, gbias = E.weight_grad(lay, blocks)
-    grad = E.unpack_grad(lay, gout, gbias)
+    assert blocks[0]["colsum"].shape == (lay.cs_size,)
+    grad = E.unpack_grad(lay, gout, gbias, sum(b["colsum"] for b in blocks))
     off = 0
     for pname, shp in lay.shapes:
         n_ = int(np.prod(shp))

@@ -301,18 +301,17 @@ def backward_wave(spec: PK.NetSpec, blob: Blob, x, d_sdf, d_n, d_rgb):
     dn2 = np.where(LH == 1, a1, a1[sw])
     nbar = np.stack([d_n[LP, 0] + dn0, d_n[LP, 1] + dn1, d_n[LP, 2] + dn2], 1)
     dsdf = d_sdf[LP]
-    k0, k1, o0, o1 = z8.copy(), z8.copy(), z8.copy(), z8.copy()
+    k0, k1 = z8.copy(), z8.copy()
     for l in range(64):
         if (l & 31) == 0:
             h = l >> 5
             for r in range(16):
                 pt = (r & 3) + 8 * (r >> 2) + 4 * h
                 if r < 8:
-                    k0[l, r], o0[l, r] = d_sdf[pt], 1.0
+                    k0[l, r] = d_sdf[pt]
                 else:
-                    k1[l, r - 8], o1[l, r - 8] = d_sdf[pt], 1.0
+                    k1[l, r - 8] = d_sdf[pt]
     panels[P["SDF"]] = (k0, k1)
-    panels[P["ONE"]] = (o0, o1)
     # phase E
     ped = st["ped"]
     gb0 = [np.zeros((64, 8)) for _ in range(3)]
@@ -320,6 +319,12 @@ def backward_wave(spec: PK.NetSpec, blob: Blob, x, d_sdf, d_n, d_rgb):
         gb0[q >> 3][:, q & 7] = ped[:, q] * nbar[:, q % 3]
     panel_store(panels, P["GB0"], gb0[0], gb0[1])
     panel_store(panels, P["GB0"] + 1, gb0[2], z8)
+    # column sums over the block's points (csrc/avc_bwd_body.h: col_sums): [ST tiles][half][16 acc registers] of gbar_hs, then
+    # [3 fragments][half][8 slots] of gbar_h0 -- the half-wave of lanes 32 h .. 32 h + 31 holds the 32 points
+    colsum = np.zeros(lay_cs_size(spec))
+    for s_ in range(3):
+        for h in range(2):
+            colsum[ST * 32 + (s_ * 2 + h) * 8: ST * 32 + (s_ * 2 + h) * 8 + 8] = gb0[s_][32 * h:32 * h + 32].sum(0)
 
     def second(offw, KS, NT, gin, hfr, qfr, ptile):
         gout, ap = [], []
@@ -327,7 +332,8 @@ def backward_wave(spec: PK.NetSpec, blob: Blob, x, d_sdf, d_n, d_rgb):
             acc = tile_gemm(blob, offw, KS, t, gin)
             gout += [acc[:, :8] * sig_from_h(hfr[2 * t]), acc[:, 8:] * sig_from_h(hfr[2 * t + 1])]
             ap += [acc[:, :8] * qfr[2 * t], acc[:, 8:] * qfr[2 * t + 1]]
-        store_act(ptile, gout, NT)
+        if ptile is not None:
+            store_act(ptile, gout, NT)
         return gout, ap
     gb1, ap1 = second("OFF_W0G", 3, HT, gb0, st["h1"], q_1, P["GBH1"])
     gbm, apm = [], []
@@ -337,7 +343,11 @@ def backward_wave(spec: PK.NetSpec, blob: Blob, x, d_sdf, d_n, d_rgb):
         gbm.append(g_out)
         apm.append(ap)
         g_in = g_out
-    gbs, aps = second("OFF_WS", HK, ST, g_in, st["hs"], q_s, P["GBHS"])
+    gbs, aps = second("OFF_WS", HK, ST, g_in, st["hs"], q_s, None)     # gbar_hs has no panel: it stays in registers ...
+    for t in range(ST):                                                 # ... and its column sums go to the wavefront's slot
+        for h in range(2):
+            for half_regs, fr in ((0, gbs[2 * t]), (8, gbs[2 * t + 1])):
+                colsum[(t * 2 + h) * 16 + half_regs: (t * 2 + h) * 16 + half_regs + 8] = fr[32 * h:32 * h + 32].sum(0)
     # phase F
     as_ = []
     for t in range(ST):
@@ -358,7 +368,12 @@ def backward_wave(spec: PK.NetSpec, blob: Blob, x, d_sdf, d_n, d_rgb):
     if NM == 2:
         am = reverse("OFF_WM1T", HK, HT, am, st["hm"][0], apm[0], P["ABM"])
     reverse("OFF_WM0T", HK, HT, am, st["h1"], ap1, P["AB1"])
+    panels["colsum"] = colsum
     return panels, (sdf, n, rgb)
+
+
+def lay_cs_size(spec):
+    return ((spec.H - 39 + 31) // 32) * 32 + 48
 
 
 def weight_grad(lay: PK.Layout, panel_blocks):
@@ -386,9 +401,11 @@ def weight_grad(lay: PK.Layout, panel_blocks):
     return gout, gbias
 
 
-def unpack_grad(lay: PK.Layout, gout, gbias):
+def unpack_grad(lay: PK.Layout, gout, gbias, colsum=None):
     grad = np.zeros(lay.nparam)
     np.add.at(grad, lay.un_tgt, gout[lay.un_src] * lay.un_scale)
     if lay.gbias_size:
         np.add.at(grad, lay.ub_tgt, gbias[lay.ub_src])
+    if colsum is not None:      # second-order term of row 0 of the last SDF layer (engine.points_bwd: cs_total)
+        np.add.at(grad, lay.cs_tgt, colsum[lay.cs_src] * lay.cs_scale)
     return grad

@@ -205,11 +205,11 @@ class Engine:
     MAX_FWD_WAVES = 2048          # persistent grid of avc_render_points_fwd: 256 CUs x one 8-wave workgroup
     MAX_BWD_WAVES = 2048          # 256 CUs x one 8-wave workgroup
     # Operand panels (csrc/avc_mlp.h: PanelLayout).  F region: 89 tiles = 5.6 KiB per point (full nets), written by the training
-    # forward for every block of a CHUNK of rays and kept until the backward pass; G region: 91 tiles = 5.7 KiB per point, one SLAB
+    # forward for every block of a CHUNK of rays and kept until the backward pass; G region: 83 tiles = 5.2 KiB per point, one SLAB
     # of at most SLAB_BLOCKS 32-point blocks, rewritten slab by slab by the backward pass (backward kernel + weight-gradient kernel
     # per slab).  Every slab boundary costs the weight-gradient launch a tail (profiles/r03_slab_sweep.txt, 512^2 x 64 spp: 1 / 2 / 4
     # / 8 slabs = 39.9 / 40.5 / 41.7 / 44.2 ms), so the slab is as large as the memory allows up to SLAB_BLOCKS and is halved
-    # (down to MIN_SLAB_BLOCKS) before the ray set is cut: 512^2 x 64 spp = 87 GiB of F panels + ONE 92-GiB slab (round 4; two 46-GiB
+    # (down to MIN_SLAB_BLOCKS) before the ray set is cut: 512^2 x 64 spp = 87 GiB of F panels + ONE 84-GiB slab (round 4; two
     # slabs before: 121.3 -> 120.6 ms per step, profiles/r04_ab_kernels.txt); 512^2 x 128 spp
     # (BASELINE config 3 per GPU) = 174 GiB + 23-GiB slabs, still ONE chunk on a 288-GB MI355X.  Only when even that does not fit
     # the budget -- min(AVC_PANEL_GIB, 80 % of the free HBM) -- the ray set is cut into chunks and the backward re-runs the

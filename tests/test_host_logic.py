@@ -200,7 +200,7 @@ def test_panel_plan_arithmetic():
     """engine.plan_panels: how a ray set is cut into chunks (F panels) and slabs (G panels) for a memory budget -- the cases of
     BASELINE's configurations on a 288-GB device and the degenerate ones"""
     from avatarclip_amd.engine import plan_panels
-    blk_f, blk_g = 89 * 2048 + 1024, 91 * 2048                      # full nets
+    blk_f, blk_g = 89 * 2048 + 1024, 83 * 2048                      # full nets (csrc/avc_mlp.h: PanelLayout)
     gib = 1 << 30
     budget = int(266 * 0.8) * gib
     nbytes = lambda rays, slab, S: ((rays * S + 31) // 32 + 1) * blk_f + ((slab * S + 31) // 32 + 1) * blk_g
@@ -222,14 +222,14 @@ def test_panel_plan_arithmetic():
     assert plan_panels(1, 64, 1 << 26, blk_f, blk_g, 256 * 1024, 32 * 1024) == (1, 1)
     assert plan_panels(33, 64, 1 << 26, blk_f, blk_g, 256 * 1024, 32 * 1024) == (33, 33)
     # one gradient slab or two is decided by the memory that is FREE, not by a constant (Engine.plan: budget = min(AVC_PANEL_GIB,
-    # 80 % of the free HBM); default slab = 512 Ki blocks): an empty 288-GB MI355X takes 512^2 x 64 spp in one 92-GiB slab
-    # (87 + 92 = 179 GiB), the same device with 100 GB held by somebody else falls back to two 46-GiB slabs, with 160 GB held to
-    # sixteen, and the view is still ONE forward chunk
+    # 80 % of the free HBM); default slab = 512 Ki blocks): an empty 288-GB MI355X takes 512^2 x 64 spp in one 84-GiB slab
+    # (87 + 84 = 172 GiB), the same device with 100 GB held by somebody else falls back to two 42-GiB slabs, with 160 GB held to
+    # eight, and the view is still ONE forward chunk
     full_dev = int(0.8 * 268 * gib)
     assert plan_panels(512 * 512, 64, min(224 * gib, full_dev), blk_f, blk_g, 512 * 1024, 32 * 1024) == (262144, 262144)
     assert plan_panels(512 * 512, 64, int(0.8 * 175 * gib), blk_f, blk_g, 512 * 1024, 32 * 1024) == (262144, 131072)
     assert plan_panels(512 * 512, 64, int(0.8 * 150 * gib), blk_f, blk_g, 512 * 1024, 32 * 1024) == (262144, 65536)
-    assert plan_panels(512 * 512, 64, int(0.8 * 125 * gib), blk_f, blk_g, 512 * 1024, 32 * 1024) == (262144, 16384)
+    assert plan_panels(512 * 512, 64, int(0.8 * 125 * gib), blk_f, blk_g, 512 * 1024, 32 * 1024) == (262144, 32768)
     chunk, slab = plan_panels(512 * 512, 64, int(0.8 * 100 * gib), blk_f, blk_g, 512 * 1024, 32 * 1024)   # below ~96 GiB the view is cut
     assert chunk < 262144 and nbytes(chunk, slab, 64) <= 80 * gib
 

@@ -115,8 +115,12 @@ __device__ __forceinline__ void weight_grad_body(char* lds, const WgRegions& rg,
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
           if (wb + WB * k < tb_n) {
+#ifdef AVC_ABL_WG_NOMFMA   // timing ablation (garbage results): the operands are streamed, transposed and converted but never contracted
+            asm volatile("" :: "v"(a[i][0]), "v"(bv[k][0]), "v"(a[i][1]), "v"(bv[k][1]));
+#else
             acc[i * NK + k] = MF<b8>::mma(a[i][0], bv[k][0], acc[i * NK + k]);
             acc[i * NK + k] = MF<b8>::mma(a[i][1], bv[k][1], acc[i * NK + k]);
+#endif
           }
         }
       }

@@ -93,3 +93,36 @@ def test_unpack_tables_as_per_parameter_lists_equal_the_scatter_statement():
         got = torch.zeros(lay.nparam, dtype=torch.float64).index_add_(0, seg, acc[src] * scl)
         assert torch.allclose(got, ref, rtol=0, atol=1e-12)
         assert int((off[1:] - off[:-1]).min()) >= 1          # every parameter of the two networks has a source
+
+
+def test_transposing_lane_reduction_of_the_column_sums():
+    """csrc/avc_bwd_body.h: transpose_sum -- NV values per lane -> ONE per lane, the sum over the half-wave's 32 lanes of value (lane & (NV - 1)):
+    every butterfly step keeps, of a pair (a, b), the one the lane's own bit selects and adds the partner's copy of the same one.  Emulated
+    on 64 lanes with the exchange partners the kernel uses (xor 1, 2 = DPP quad permutes; xor 4, 8, 16 = ds_bpermute)."""
+    rs = np.random.RandomState(0)
+    lane = np.arange(64)
+
+    def transpose_sum(v):                      # v [64 lanes, NV]
+        nv = v.shape[1]
+        vals = [v[:, k] for k in range(nv)]
+        bit = 0
+        while len(vals) > 1:                   # xor 1, 2, 4 (, 8)
+            b = (lane >> bit) & 1
+            partner = lane ^ (1 << bit)
+            nxt = []
+            for k in range(len(vals) // 2):
+                keep = np.where(b == 1, vals[2 * k + 1], vals[2 * k])
+                give = np.where(b == 1, vals[2 * k], vals[2 * k + 1])
+                nxt.append(keep + give[partner])
+            vals, bit = nxt, bit + 1
+        z = vals[0]
+        while bit < 5:                         # the remaining exchanges up to xor 16: plain sums
+            z = z + z[lane ^ (1 << bit)]
+            bit += 1
+        return z
+    for nv in (8, 16):
+        v = rs.randn(64, nv)
+        z = transpose_sum(v)
+        for l in range(64):
+            half = slice(32 * (l >> 5), 32 * (l >> 5) + 32)
+            assert abs(z[l] - v[half, l & (nv - 1)].sum()) < 1e-12

@@ -163,7 +163,7 @@ __device__ __forceinline__ void cs_flush(cs_slot_t slot, float* out, long row, i
 #ifndef AVC_BWD_PIPE_IN
 #define AVC_BWD_PIPE_IN 1   // (profiles/r05_ab_kernels.txt: 9.81 -> 9.48 ms per 4 Mi points)
 #endif
-template <class N> struct BlkIn { b8 dof; unsigned m1[N::HT], m2[N::HT]; };
+template <class N> struct BlkIn { b8 dof; unsigned m1[N::HT], m2[N::HT]; float dn[3], dsdf; };   // (+ the cotangents d_normal, d_sdf: used mid-block, behind barriers no load can be hoisted over)
 template <class N>
 __device__ __forceinline__ void load_blk_in(const BwdArgs& a, long blk, long nblk, int lane, BlkIn<N>& bi) {
   typedef PanelLayout<N> L;
@@ -187,6 +187,9 @@ __device__ __forceinline__ void load_blk_in(const BwdArgs& a, long blk, long nbl
     bi.m1[t] = mk[t * 64];
     bi.m2[t] = (N::NCMID == 1) ? mk[(N::HT + t) * 64] : 0u;
   }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) bi.dn[c] = a.d_normal[3 * i + c] * vmask;
+  bi.dsdf = a.d_sdf[i] * vmask;
 }
 
 struct NoRing {
@@ -227,6 +230,7 @@ __device__ __forceinline__ void bwd_sweeps(StageT<BWD_G>& sg, const BwdArgs& a, 
   // ------------------------------------------------------------------ phase D: colour backward (bf16)
   // delta_o = d_rgb * rgb (1 - rgb) with the colours of the forward pass; half 0: outputs 0..3, half 1: outputs 4,5
   float nbar[3];
+  float dsdf_in;
   {
     BlkIn<N> bi_local;
     if constexpr (!PIPE) load_blk_in<N>(a, blk, nblk, lane, bi_local);
@@ -237,6 +241,8 @@ __device__ __forceinline__ void bwd_sweeps(StageT<BWD_G>& sg, const BwdArgs& a, 
     unsigned m1[N::HT], m2[N::HT];
 #pragma unroll
     for (int t = 0; t < N::HT; ++t) { m1[t] = bi.m1[t]; m2[t] = bi.m2[t]; }
+    const float dn_in[3] = {bi.dn[0], bi.dn[1], bi.dn[2]};
+    dsdf_in = bi.dsdf;
 #define AVC_RELU_BWD(OUT, MSK, PT)                                                                         \
   AVC_EPI(const unsigned bits = MSK[t];                                                                      \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                    \
@@ -268,12 +274,12 @@ __device__ __forceinline__ void bwd_sweeps(StageT<BWD_G>& sg, const BwdArgs& a, 
       // row 3 -> (h0,r3), row 4 -> (h1,r0), row 5 -> (h1,r1)
       const float a3 = dn_acc[0], a0 = dn_acc[1], a1 = dn_acc[2];
       const float o3 = __shfl_xor(a3, 32), o0 = __shfl_xor(a0, 32), o1 = __shfl_xor(a1, 32);
-      nbar[0] = a.d_normal[3 * i + 0] * vmask + (h ? o3 : a3);
-      nbar[1] = a.d_normal[3 * i + 1] * vmask + (h ? a0 : o0);
-      nbar[2] = a.d_normal[3 * i + 2] * vmask + (h ? a1 : o1);
+      nbar[0] = dn_in[0] + (h ? o3 : a3);
+      nbar[1] = dn_in[1] + (h ? a0 : o0);
+      nbar[2] = dn_in[2] + (h ? a1 : o1);
     }
   }
-  const float dsdf = a.d_sdf[i] * vmask;
+  const float dsdf = dsdf_in;
   const float dsdfS = dsdf * AVC_S;   // OFF_WL0_ACC holds W_last[0,:]/(S sqrt2): undo S for the gradient use
   {   // operand tile with two live features: d_sdf (row 0 of the last layer), slots (half 0, j = 0, 1)
     b8 fs = zero_frag<b8>();

@@ -364,6 +364,14 @@ def main():
             "roofline": roofs.get(dominant),
             "roofline_all": roofs,
         }
+        # Some boxes of the pool sustain only ~3.9 TB/s of MIXED read + write HBM traffic (6 elsewhere); the backward kernel is the one
+        # kernel of the step above that ceiling and then takes ~1.45 x as long as the weight-gradient launch instead of ~1.0 x
+        # (profiles/r05_slow_box.md: same bytes by PMC, the waves wait at 2.3 GHz).  Say so in the line instead of leaving a riddle.
+        kb, kw = kern_ms.get("avc_render_points_bwd"), kern_ms.get("avc_weight_grad(all pairs)")
+        if kb and kw and kb > 1.25 * kw:
+            out["box_note"] = ("mlp_bwd_kernel %.1f ms vs weight_grad_all_kernel %.1f ms: this box caps mixed read+write HBM traffic "
+                               "(profiles/r05_slow_box.md); on the other boxes the two are equal and the step is ~%.0f ms shorter"
+                               % (kb, kw, kb - kw))
     # ---- extra_configs (rank 0 of a single-GPU run): BASELINE config 2 (224^2, 64 spp) and config 3's per-GPU share (512^2, 128 spp)
     if world == 1 and not args.no_extra and not args.small and (args.res, args.spp) == (512, 64):
         import gc

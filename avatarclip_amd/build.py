@@ -44,7 +44,8 @@ def _gen_offsets():
 def build(force: bool = False, verbose: bool = False, ring: bool = False) -> str:
     """libavc.so (or $AVC_LIB_NAME); ring=True: libavc_ring.so = the same objects + csrc/avc_bwd_ring.hip"""
     _gen_offsets()
-    ring = ring or os.environ.get("AVC_WITH_RING", "0") == "1"
+    # AVC_LIB_NAME=libavc_ring.so makes LIB the ring library's path: a plain build() must then not relink it without its ring object
+    ring = ring or os.environ.get("AVC_WITH_RING", "0") == "1" or os.path.basename(LIB) == os.path.basename(RING_LIB)
     target = RING_LIB if ring else LIB
     srcs = [s for s in SOURCES + ([RING_SOURCE] if ring else []) if os.path.exists(os.path.join(CSRC, s))]
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
@@ -67,7 +68,9 @@ def build(force: bool = False, verbose: bool = False, ring: bool = False) -> str
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(run, jobs))
     if jobs or force or _stale(target, objs):
-        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs)
+        tmp = "%s.%d.tmp" % (target, os.getpid())       # concurrent builders: nobody ever maps a half-written library
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs)
+        os.replace(tmp, target)
     return target
 
 

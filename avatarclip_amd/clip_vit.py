@@ -261,6 +261,7 @@ class ClipVisionB32:
         self._packed = {}
         self._graphed = {}
         self._graph_busy = {}         # batch size -> a replayed forward is waiting for its backward
+        self._graph_gen = {}          # batch size -> number of replays so far (a backward checks it still owns the static activations)
         self._warned_busy = False
         self._graph_ws = []           # packing workspaces the captured launches point at
 
@@ -363,9 +364,17 @@ class ClipVisionB32:
                               "iteration; other callers: release_graphs())" % B, RuntimeWarning, stacklevel=2)
             if g is not False and not self._graph_busy.get(B, False):
                 self._graph_busy[B] = True
+                gen = self._graph_gen[B] = self._graph_gen.get(B, 0) + 1
                 out = g(image.float())
 
-                def _release(grad, B=B):
+                def _release(grad, B=B, gen=gen):
+                    # the instance's static activations belong to its LATEST replay: a backward that arrives for an earlier one (its
+                    # forward was declared finished by release_graphs() and the graph replayed since) would differentiate the newer
+                    # call's activations -- silently wrong pixel gradients.  Refuse it.
+                    if self._graph_gen[B] != gen:
+                        raise RuntimeError("ClipVisionB32: backward of a graph-replayed encode_image (batch %d, replay %d) after release_graphs() "
+                                           "and a later replay (%d) overwrote its captured activations; run that backward before the next "
+                                           "iteration, or take the loss with TRAIN_GRAPH off" % (B, gen, self._graph_gen[B]))
                     self._graph_busy[B] = False
                     return grad
                 out.register_hook(_release)

@@ -274,9 +274,11 @@ __device__ __forceinline__ void bwd_sweeps(StageT<BWD_G>& sg, const BwdArgs& a, 
       // row 3 -> (h0,r3), row 4 -> (h1,r0), row 5 -> (h1,r1)
       const float a3 = dn_acc[0], a0 = dn_acc[1], a1 = dn_acc[2];
       const float o3 = __shfl_xor(a3, 32), o0 = __shfl_xor(a0, 32), o1 = __shfl_xor(a1, 32);
-      nbar[0] = dn_in[0] + (h ? o3 : a3);
-      nbar[1] = dn_in[1] + (h ? a0 : o0);
-      nbar[2] = dn_in[2] + (h ? a1 : o1);
+      // (lanes past the last point: exact zeros by SELECTION, not by 0 * x -- everything the second-order sweep and the unmasked column
+      // sums of gbar_h0 / gbar_hs derive from nbar is then zero whatever the colour sweep left in those lanes)
+      nbar[0] = valid ? dn_in[0] + (h ? o3 : a3) : 0.f;
+      nbar[1] = valid ? dn_in[1] + (h ? a0 : o0) : 0.f;
+      nbar[2] = valid ? dn_in[2] + (h ? a1 : o1) : 0.f;
     }
   }
   const float dsdf = dsdf_in;

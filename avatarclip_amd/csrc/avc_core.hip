@@ -7,7 +7,7 @@
 static thread_local char g_err[512] = "";
 
 extern "C" const char* avc_last_error(void) { return g_err; }
-extern "C" int avc_version(void) { return 1; }
+extern "C" int avc_version(void) { return AVC_ABI_VERSION; }
 extern "C" int avc_num_offsets(void) { return OFF_COUNT; }
 
 void avc_set_error(const char* msg) {

@@ -319,7 +319,10 @@ class Engine:
             buf = None                   # release the old buffer BEFORE the larger one is allocated (peak = need, not have + need):
             setattr(self, attr, None)    # neither the attribute nor this local may keep it alive across empty_cache()
             torch.cuda.empty_cache()
-            buf = torch.empty(n, dtype=dtype, device=self.device)
+            # zero-filled once (~20 ms per 100 GiB, only when a buffer grows): wavefronts past the last block read the sink block of the F
+            # region and multiply their (zero) cotangents with what they find there -- the forward has always written it by then, but no
+            # byte of a panel buffer may ever be an uninitialised NaN pattern
+            buf = torch.zeros(n, dtype=dtype, device=self.device)
             setattr(self, attr, buf)
         return buf
 
@@ -332,11 +335,11 @@ class Engine:
         return self._grow("_gpanels", (nblk_slab + 1) * self.grad_tiles * 2048)
 
     def _ring_setup(self):
+        """buffers + pair tables of the role-specialised backward: (ctl, payload, partial, bias_partial, pb_tiles, pairs of the
+        remaining weight-gradient launch, [(out_off, bias_off)] of the ring products)"""
         if not L.has_ring():
             raise RuntimeError("AVC_BWD_RING=1 needs libavc_ring.so (python -m avatarclip_amd.build --ring; AVC_LIB_NAME=libavc_ring.so): the "
                                "role-specialised backward is an experiment that is not part of libavc.so (include/avc_ring.h)")
-        """buffers + pair tables of the role-specialised backward: (ctl, payload, partial, bias_partial, pb_tiles, pairs of the
-        remaining weight-gradient launch, [(out_off, bias_off)] of the ring products)"""
         key = (self.RING_CPT, self.RING_SLOTS)
         if self._ring is not None and self._ring["key"] == key:
             return self._ring
@@ -603,9 +606,10 @@ class Engine:
                 grad.index_add_(0, self.dl.ub_tgt, gbias[self.dl.ub_src])
         if cs_total is not None:      # second-order term of row 0 of the last SDF layer: sum_points [gbar_hs ; gbar_h0] / sqrt2 (unique targets)
             grad.index_add_(0, self.dl.cs_tgt, cs_total[self.dl.cs_src] * self.dl.cs_scale)
-        # (d loss / d (sdf bias) = sum of d_sdf over all points cancels heavily -- the eikonal term pulls both ways -- and a single bf16
-        # slot of d_sdf used to get it wrong by several percent; the tile now carries d_sdf as hi + lo, see packing.py / avc_bwd_body.h.
-        # AVC_SDF_BIAS_FP32=1 restores the old override from the fp32 tensor for A/B.)
+        # (d loss / d (sdf bias) = sum of d_sdf over all points cancels heavily -- the eikonal term pulls both ways.  The tile carries d_sdf
+        # as hi + lo bf16 (packing.py / avc_bwd_body.h) and gets it to 0.03 %; the default takes the sum from the fp32 cotangent instead,
+        # AVC_SDF_BIAS_FP32=0 leaves the products' value.  sdf = lin_out / scale (fields.py:93) with scale == 1: packing.spec_from_conf
+        # refuses every other value, so no division is needed here.)
         if self.SDF_BIAS_FP32:
             grad[self._sdf_bias0] = d_sdf.sum()
         if rg is not None:   # a hand-off that timed out leaves the products incomplete: make that loud without a host round trip

@@ -8,6 +8,7 @@ import torch
 from . import build as _build
 
 _lib = None
+ABI_VERSION = 2          # AVC_ABI_VERSION of include/avc.h this binding was written against
 
 c_int, c_long, c_float, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
 P = c_void_p
@@ -104,6 +105,10 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+    got = lib.avc_version()
+    if got != ABI_VERSION:
+        raise RuntimeError("%s implements revision %d of include/avc.h, this binding expects %d: rebuild the library "
+                           "(python -m avatarclip_amd.build --force)" % (path, got, ABI_VERSION))
     _lib = lib
     return lib
 

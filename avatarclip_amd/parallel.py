@@ -60,13 +60,14 @@ def gpu_numa_nodes(sysfs="/sys"):
                 nodes.append(int(f.read().strip()))
         except (OSError, ValueError):
             nodes.append(-1)
-    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
-        vis = os.environ.get(var)
+    # ROCR_VISIBLE_DEVICES filters what the runtime enumerates; HIP_VISIBLE_DEVICES (CUDA_VISIBLE_DEVICES is its alias) then indexes
+    # into THAT list -- the two compose, in this order
+    for var in ("ROCR_VISIBLE_DEVICES", ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")):
+        vis = os.environ.get(var) if isinstance(var, str) else (os.environ.get(var[0]) or os.environ.get(var[1]))
         if vis and all(t.strip().isdigit() for t in vis.split(",")):
             idx = [int(t) for t in vis.split(",")]
             if all(i < len(nodes) for i in idx):
                 nodes = [nodes[i] for i in idx]
-            break
     return nodes
 
 

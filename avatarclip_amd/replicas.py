@@ -32,6 +32,21 @@ def plan(n, gpus, allowed_cores, gpu_nodes=None, node_cpus=None):
     return [(dev[i], parallel.core_slice(i, n, allowed_cores, nodes, node_cpus)) for i in range(n)]
 
 
+def child_visibility(gpu, env):
+    """The device-visibility variables of the child that owns ordinal `gpu` OF THE PARENT'S VISIBLE SET (what torch.cuda.device_count()
+    counts and parallel.gpu_numa_nodes() describes).  HIP_VISIBLE_DEVICES (alias CUDA_VISIBLE_DEVICES) indexes into what
+    ROCR_VISIBLE_DEVICES leaves, so the parent's ROCR list is KEPT and the parent's HIP list is translated: under a scheduler's
+    ROCR_VISIBLE_DEVICES=4,5,6,7 or HIP_VISIBLE_DEVICES=2,3 replica 0 lands on physical GPU 4 / 2, not on somebody else's GPU 0.
+    Pure function: returns (updates, names to remove)."""
+    vis = env.get("HIP_VISIBLE_DEVICES") or env.get("CUDA_VISIBLE_DEVICES")
+    if vis:
+        toks = [t.strip() for t in vis.split(",") if t.strip()]
+        if not 0 <= gpu < len(toks):
+            raise ValueError("replica device ordinal %d is outside the parent's visible devices %r" % (gpu, vis))
+        return {"HIP_VISIBLE_DEVICES": toks[gpu]}, ("CUDA_VISIBLE_DEVICES",)
+    return {"HIP_VISIBLE_DEVICES": str(gpu)}, ("CUDA_VISIBLE_DEVICES",)
+
+
 def launch_commands(commands, gpus=None, log_dir=None, env=None, wait=True):
     """Start one child per command (argv lists), replica i pinned to plan()[i].  Returns the list of return codes (wait=True) or the
     Popen objects."""
@@ -57,9 +72,11 @@ def launch_commands(commands, gpus=None, log_dir=None, env=None, wait=True):
         os.makedirs(log_dir, exist_ok=True)
     procs = []
     for i, (cmd, (gpu, cores)) in enumerate(zip(commands, layout)):
-        e = dict(base, HIP_VISIBLE_DEVICES=str(gpu), AVC_REPLICA=str(i), OMP_NUM_THREADS=str(max(1, min(len(cores), 16))))
-        e.pop("ROCR_VISIBLE_DEVICES", None)
-        e.pop("CUDA_VISIBLE_DEVICES", None)
+        e = dict(base, AVC_REPLICA=str(i), OMP_NUM_THREADS=str(max(1, min(len(cores), 16))))
+        upd, drop = child_visibility(gpu, base)
+        e.update(upd)
+        for k in drop:
+            e.pop(k, None)
         out = open(os.path.join(log_dir, "replica_%d.log" % i), "w") if log_dir else None
 
         def pin(cores=cores):
@@ -83,7 +100,7 @@ def launch(confs, gpus=None, mode="train_clip", extra_args=(), log_dir=None, env
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("--confs", nargs="+", required=True, help="one conf per replica (one prompt / avatar each)")
-    ap.add_argument("--gpus", type=str, default=None, help="comma-separated device ordinals (default: all visible devices)")
+    ap.add_argument("--gpus", type=str, default=None, help="comma-separated device ordinals within this process's visible devices (default: all of them)")
     ap.add_argument("--mode", type=str, default="train_clip")
     ap.add_argument("--log_dir", type=str, default="./replica_logs")
     ap.add_argument("extra", nargs=argparse.REMAINDER, help="flags passed through to avatarclip_amd.main after `--`")

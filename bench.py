@@ -310,12 +310,17 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     collective = "none (single process, no process group)"
+    ranks_seen = {"backend": None, "ranks": 1, "devices": sorted({local_rank})}
     if parallel.is_on():
         import torch.distributed as dist
         be = dist.get_backend()
         collective = "%s%s, %d rank(s)" % (be, " (RCCL)" if be == "nccl" else "", world)
         want = os.environ.get("AVC_ASSERT_DIST")
         assert not want or want == be, "process group backend %s, expected %s" % (be, want)
+        # what the process group itself reports (not what was asked for): its size, and the device ordinal every rank ended up on
+        devs = [None] * world
+        dist.all_gather_object(devs, int(local_rank))
+        ranks_seen = {"backend": be, "ranks": dist.get_world_size(), "devices": devs}
 
     torch.cuda.reset_peak_memory_stats(dev)
     free0, total0 = torch.cuda.mem_get_info(dev)
@@ -358,6 +363,8 @@ def main():
                                       "small (128-wide)" if args.small else "full-size (256-wide)", world),
                        "parallelism": "view-sharded dp%d, one flat RCCL all-reduce/step" % world,
                        "collective": collective},
+            "rccl_ranks_seen": ranks_seen["ranks"] if ranks_seen["backend"] == "nccl" else 0,
+            "process_group": ranks_seen,
             "kernel_ms_per_step": kern_ms,
             # whole step against the MFMA roofline: algorithmic MLP FLOPs of the step (257.3 MFLOP/ray at 64 spp) / step time
             "step_mfma_frac": (step_flops(args.res, args.spp) * args.steps / dt / PEAK_MFMA) if not args.small else None,

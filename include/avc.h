@@ -22,6 +22,12 @@ extern "C" {
 #define AVC_NET_FULL 0  /* confs/examples (all 144):   SDF 39-256-256-256-217(+39)-257, colour 262-256-256-{3,3} */
 #define AVC_NET_SMALL 1 /* confs/examples_small:        SDF 39-128-128-89(+39)-129,     colour 134-128-{3,3}     */
 
+/* Interface revision of this header.  It changes whenever an existing entry point's argument list or meaning changes (2: round 5 put
+ * `colsum` into avc_render_points_bwd and moved the second-order row-0 term out of the weight-gradient products), so a caller built
+ * against an older header can refuse the library instead of passing arguments in the wrong slots:
+ *     if (avc_version() != AVC_ABI_VERSION) abort();       (avatarclip_amd/lib.py: load() does exactly this) */
+#define AVC_ABI_VERSION 2
+
 const char* avc_last_error(void);
 int avc_version(void);
 /* number of int32 slots in the `offs` arrays below (== OFF_COUNT of csrc/avc_common.h) */

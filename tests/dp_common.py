@@ -46,14 +46,26 @@ def build_runner(device, res, spp, use_oracle_kernels):
     return r
 
 
-def worker(rank, world, port, out, device_kind, res, spp):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
-                      AVC_DIST_BACKEND="gloo")
-    if device_kind == "cuda":   # all ranks share device 0: keep the hardware queues from being oversubscribed (see bench.py's spawner)
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+def worker(rank, world, port, out, device_kind, res, spp, backend="gloo"):
+    """backend "gloo": collectives on the host, every rank on device 0 (1-GPU boxes, CPU tests); backend "nccl" (= RCCL): one device per
+    rank, the product's layout on a node"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "gloo":
+        os.environ["AVC_DIST_BACKEND"] = "gloo"
+        if device_kind == "cuda":   # all ranks share device 0: keep the hardware queues from being oversubscribed (see bench.py's spawner)
+            os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+    else:
+        os.environ.pop("AVC_DIST_BACKEND", None)
+        os.environ.pop("AVC_SINGLE_DEVICE", None)
     from avatarclip_amd import parallel
-    parallel.init_from_env(backend="gloo")
-    device = torch.device("cuda", 0) if device_kind == "cuda" else torch.device("cpu")   # all ranks share device 0 (development aid)
+    parallel.init_from_env(backend=backend)
+    if backend == "nccl":
+        assert device_kind == "cuda" and torch.distributed.get_backend() == "nccl" and torch.cuda.device_count() >= world
+        device = torch.device("cuda", rank)
+        torch.cuda.set_device(device)
+    else:
+        device = torch.device("cuda", 0) if device_kind == "cuda" else torch.device("cpu")   # all ranks share device 0 (development aid)
     r = build_runner(device, res, spp, use_oracle_kernels=(device_kind != "cuda"))
     assert r.world == world and r.rank == rank and r.grad_bucket is not None
     w0 = [p.detach().cpu().clone() for p in r.params_to_train]
@@ -62,7 +74,8 @@ def worker(rank, world, port, out, device_kind, res, spp):
     res_ = dict(eye=np.asarray(v.eye), at=np.asarray(v.at), loss=float(loss), data_seed=r.data_seed, w0=w0,
                 grads=[p.grad.detach().cpu().clone() for p in r.params_to_train],
                 params=[p.detach().cpu().clone() for p in r.params_to_train],
-                bucket_is_grad=all(p.grad.data_ptr() == g.data_ptr() for p, g in zip(r.params_to_train, r.grad_bucket.views)))
+                bucket_is_grad=all(p.grad.data_ptr() == g.data_ptr() for p, g in zip(r.params_to_train, r.grad_bucket.views)),
+                device=str(device), backend=torch.distributed.get_backend(), ranks_seen=torch.distributed.get_world_size())
     if isinstance(out, str):    # a directory: one file per rank (eight ranks answering a Manager at once overran its listener)
         torch.save(res_, os.path.join(out, "rank%d.pt" % rank))
     else:

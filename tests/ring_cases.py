@@ -70,31 +70,3 @@ def test_ring_backward_equals_the_panel_path(small, R, S, cpt, slots):
                 assert rel < 2e-5, (name, rel, rep)       # same products, different summation order (fp32)
     finally:
         Engine.RING, Engine.RING_CPT, Engine.RING_SLOTS, Engine.RING_CHECK = old
-
-
-@gpu
-@pytest.mark.parametrize("small,R,S,slab_blocks", [(True, 257, 48, None), (False, 4096, 64, None), (False, 4096, 64, 2048)])
-def test_fused_split_sums_and_unpacking_equal_the_torch_statement(small, R, S, slab_blocks, monkeypatch):
-    """avc_weight_grad_reduce + avc_weight_grad_unpack (one launch per slab + one at the end) against the torch statement of the same
-    arithmetic (two reductions + two adds per slab, gather, scale, two index_adds): same products, fp32 sums in a different order;
-    with several slabs the accumulate path is exercised."""
-    from avatarclip_amd.engine import Engine
-    dev = torch.device("cuda")
-    ren = _nets(small, dev)
-    eng = ren.engine
-    if slab_blocks is not None:
-        monkeypatch.setattr(eng, "plan", lambda R_, S_: (R_, slab_blocks * 32 // S_))
-    pk = eng.pack(ren.flat_params())
-    ro, rd, z, dsdf, dn, drgb = _inputs(R, S, dev)
-    gs = []
-    for fused in (False, True):
-        monkeypatch.setattr(Engine, "FUSED_WG_TAIL", fused)
-        _, _, rgbf = eng.points_fwd_train(pk, ro, rd, z, 2 / 32)
-        gs.append(eng.points_bwd(pk, ro, rd, z, 2 / 32, dsdf, dn, drgb, rgbf, panels_valid=True).clone())
-    lay = eng.dl.lay
-    assert torch.isfinite(gs[1]).all()
-    for name, shape in lay.shapes:
-        n = int(np.prod(shape))
-        a, b = (g[lay.pbase[name]:lay.pbase[name] + n] for g in gs)
-        rel = float((a - b).norm() / (a.norm() + 1e-30))
-        assert rel < 2e-6, (name, rel)

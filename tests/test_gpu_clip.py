@@ -253,6 +253,18 @@ def test_two_calls_before_one_backward_do_not_share_the_captured_instance(monkey
             assert torch.equal(res[(True, rnd)][0][k], res[(False, rnd)][0][k]), (rnd, k)
             assert torch.equal(res[(True, rnd)][1][k], res[(False, rnd)][1][k]), (rnd, k)
     assert not torch.equal(res[(True, 0)][0][0], res[(True, 0)][0][1])
+    # a loss held ACROSS release_graphs() and a later replay: its backward would differentiate the newer call's captured
+    # activations -- it must raise instead of returning wrong pixel gradients; the newer call's own backward is unaffected
+    monkeypatch.setattr(V, "TRAIN_GRAPH", True)
+    x_old, x_new = imgs[0].clone().requires_grad_(True), imgs[1].clone().requires_grad_(True)
+    held = model.encode_image(x_old).sum()
+    model.release_graphs()
+    newer = model.encode_image(x_new)
+    assert model._graph_gen[1] >= 2
+    with pytest.raises(RuntimeError, match="release_graphs"):
+        held.backward()
+    (1 - torch.cosine_similarity(newer.mean(0), text.mean(0), dim=0)).backward()
+    assert torch.equal(x_new.grad, res[(False, 0)][1][1]) and model._graph_busy.get(1) is False
 
 
 @gpu

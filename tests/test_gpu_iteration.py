@@ -70,7 +70,8 @@ def _check_grads(names, grads_a, grads_b, sdf_last_bias, rel_tol, cos_tol, bias_
     return worst
 
 
-def _run_parity(res, spp, iters, small, silhouettes=False, rel_tol=2e-2, cos_tol=0.999, bias_tol=0.05, loss_tol=2e-3):
+def _run_parity(res, spp, iters, small, silhouettes=False, rel_tol=2e-2, cos_tol=0.999, bias_tol=0.05, loss_tol=2e-3, warm_up_end=0,
+                start_step=0):
     from oracle import iteration_oracle as IT
     from oracle import neus_oracle as O
     from avatarclip_amd.runner import clip_vit_random_state_dict, EllipsoidPrior
@@ -79,7 +80,11 @@ def _run_parity(res, spp, iters, small, silhouettes=False, rel_tol=2e-2, cos_tol
     over = {}
     if silhouettes:
         over = {"train.use_silhouettes": True, "train.max_ray_num": 900, "dataset.H": 256, "dataset.W": 256}
+    if warm_up_end:
+        over["train.warm_up_end"] = warm_up_end
     a = _make_runner(dev, res, spp, small, **over)
+    a.iter_step = start_step
+    assert a.warm_up_end == warm_up_end
     a.init_clip(clip_state_dict=clip_sd)
     prior = EllipsoidPrior(device="cpu")
     cams = [(np.array([0.35, 0.25, 1.45], np.float32), np.array([0.02, -0.03, 0.01], np.float32), 0.3, 1.2, 1),
@@ -93,7 +98,8 @@ def _run_parity(res, spp, iters, small, silhouettes=False, rel_tol=2e-2, cos_tol
     sd_c = {n: p.detach().cpu().clone().requires_grad_() for n, p in a.color_network.named_parameters()}
     var = a.deviation_network.variance.detach().cpu().clone().requires_grad_()
     st = IT.OracleState(sd_s, sd_c, var, lr0=a.learning_rate, alpha=a.learning_rate_alpha, warm_up_end=a.warm_up_end,
-                        end_iter=a.end_iter)
+                        end_iter=a.end_iter, iter_step=start_step)
+    assert abs(st.opt.param_groups[0]["lr"] - a.optimizer.param_groups[0]["lr"]) < 1e-12
     texts = dict(prompt=a.encoded_text.cpu(), face_prompt=a.encoded_face_text.cpu(), back_prompt=a.encoded_back_text.cpu())
     oconf = _oracle_conf(a, a.dataset.H)
     names = [n for net in (a.sdf_network, a.deviation_network, a.color_network) for n, _ in net.named_parameters()]
@@ -129,6 +135,9 @@ def _run_parity(res, spp, iters, small, silhouettes=False, rel_tol=2e-2, cos_tol
         for pa, pb in zip(w_before, wo_before):       # the two legs start every iteration from (nearly) the same weights
             assert (pa - pb).abs().max() <= 2.5 * a.learning_rate
         lr_used = a.optimizer.param_groups[0]["lr"]
+        if warm_up_end:      # the linear ramp of main.py:577-580, both legs
+            assert abs(lr_used - a.learning_rate * (start_step + i) / warm_up_end) < 1e-12 and start_step + i < warm_up_end
+            assert abs(st.opt.param_groups[0]["lr"] - lr_used) < 1e-12
         la = a.train_clip_iteration(i, camera=cams[i])
         grads_a = [p.grad.detach().cpu().clone() for p in a.params_to_train]
         a.update_learning_rate()
@@ -178,6 +187,20 @@ def test_train_clip_iteration_matches_independent_oracle_iteration_small_nets():
 def test_train_clip_iteration_matches_independent_oracle_iteration_full_size_nets():
     """BASELINE config 1 geometry (64 x 64 rays, S = I = 32) with the 256-wide networks of confs/examples."""
     _run_parity(res=64, spp=64, iters=1, small=False)
+
+
+@gpu
+def test_train_clip_iteration_at_128_samples_per_ray_matches_independent_oracle_iteration():
+    """BASELINE config 3's sampling regime: 64 coarse + 64 importance samples per ray in four steps of 16 (the 32-lane up-sampling
+    kernel, S = 128 rows through the training forward, the compositing scans and both backward kernels), full-size nets."""
+    _run_parity(res=32, spp=128, iters=1, small=False)
+
+
+@gpu
+def test_train_clip_iterations_inside_the_learning_rate_warm_up():
+    """main.py:571-586's linear warm-up branch (every other parity leg runs with warm_up_end = 0): two iterations at steps 3 and 4 of a
+    10-step ramp; the Adam displacements are compared against the oracle's at the ramp's learning rates."""
+    _run_parity(res=32, spp=32, iters=2, small=True, warm_up_end=10, start_step=3)
 
 
 @gpu

@@ -43,7 +43,8 @@ def _setup(name):
     col.load_state_dict(sd_col)
     var.load_state_dict({"variance": variance})
     sdf, col, var = sdf.to(dev), col.to(dev), var.to(dev)
-    ren = renderer.NeuSRenderer(None, sdf, var, col, n_samples=32, n_importance=32, n_outside=0, up_sample_steps=4,
+    n0 = rec["up0_z_in"].shape[1]          # 32 (AG/confs) or 64 (neus_full_128.npz: BASELINE config 3, 64 + 64 samples per ray)
+    ren = renderer.NeuSRenderer(None, sdf, var, col, n_samples=n0, n_importance=n0, n_outside=0, up_sample_steps=4,
                                 perturb=1.0, extra_color=True)
     return rec, sd_sdf, sd_col, variance, sdf, col, var, ren, dev
 
@@ -120,14 +121,19 @@ def test_sdf_and_point_forward(name):
 
 
 @gpu
-@pytest.mark.parametrize("name", ["neus_small.npz", "neus_full.npz"])
+@pytest.mark.parametrize("name", ["neus_small.npz", "neus_full.npz", "neus_full_128.npz"])
 def test_upsample_steps_match_reference(name):
+    """avc_upsample_step against the per-step intermediates of the reference's own up_sample / cat_z_vals (renderer.py:133-193, 39-69):
+    n = 32..56, m = 8 (the 16-lane-per-ray kernel) and, neus_full_128.npz, BASELINE config 3's n = 64, 80, 96, 112 with m = 16 (the
+    32-lane-per-ray kernel)"""
     rec, sd_sdf, sd_col, variance, sdf, col, var, ren, dev = _setup(name)
     eng = ren.engine
     ro, rd = rec["rays_o"].to(dev), rec["rays_d"].to(dev)
+    m = rec["up0_new_z"].shape[1]
+    assert (rec["up0_z_in"].shape[1], m) == ((64, 16) if "128" in name else (32, 8))
     for i in range(4):
         z_in, sdf_in = rec["up%d_z_in" % i].to(dev).contiguous(), rec["up%d_sdf_in" % i].to(dev).contiguous()
-        z_out, sdf_out, z_new, slot = eng.upsample_step(ro, rd, z_in, sdf_in, 8, 64 * 2 ** i)
+        z_out, sdf_out, z_new, slot = eng.upsample_step(ro, rd, z_in, sdf_in, m, 64 * 2 ** i)
         torch.cuda.synchronize()
         ref_new = rec["up%d_new_z" % i]
         err = (z_new.cpu() - ref_new).abs()
@@ -148,7 +154,7 @@ def test_composite_forward_backward_fp32():
     dev = torch.device("cuda")
     eng = engine.Engine(PK.SMALL, dev)
     g = torch.Generator().manual_seed(0)
-    for (R, S, bg_mode) in ((37, 64, 1), (5, 128, 2), (130, 33, 0)):
+    for (R, S, bg_mode) in ((37, 64, 1), (5, 128, 2), (130, 33, 0), (41, 128, 1), (19, 64, 2), (7, 128, 0)):
         z = torch.sort(torch.rand(R, S, generator=g) * 2 + 0.5, dim=-1)[0]
         sdf = torch.randn(R, S, generator=g) * 0.05
         n = torch.randn(R, S, 3, generator=g)
@@ -186,8 +192,7 @@ def test_composite_forward_backward_fp32():
         d_n_tot = d_n_up + cf["w"].float()[..., None] * d_nsum[:, None, :]
         cb = A.composite_backward(cf, sdf.double(), n.double(), rgb.double(), rd.double(), inv_s.double(), car,
                                   None if bgr is None else (bgr.double() if bg_mode == 1 else bgr.double().expand(R, 3)),
-                                  d_color.double(), d_extra.double(), d_w_tot.double(), d_n_tot.double(), d_eik.double()) \
-            if bg_mode != 2 else None
+                                  d_color.double(), d_extra.double(), d_w_tot.double(), d_n_tot.double(), d_eik.double())
         eik_scale = (d_eik / cf["eik_den"].float()).reshape(1)
         bo = eng.composite_bwd(D(sdf), D(n), D(rgb), D(z), D(ro), D(rd), D(inv_s), sd, car, D(bg), bg_mode, D(d_color),
                                D(d_extra), D(d_w), D(d_n_up), D(eik_scale), D(d_wsum), D(d_nsum))
@@ -205,9 +210,10 @@ def test_composite_forward_backward_fp32():
 
 
 @gpu
-@pytest.mark.parametrize("name", ["neus_small.npz", "neus_full.npz"])
+@pytest.mark.parametrize("name", ["neus_small.npz", "neus_full.npz", "neus_full_128.npz"])
 def test_render_matches_golden_on_reference_z(name):
-    """Rendered RGB / weights vs the reference's own render (golden fixture) on identical rays, weights and z."""
+    """Rendered RGB / weights vs the reference's own render (golden fixture) on identical rays, weights and z.  Grad mode is on, so
+    this is the TRAINING forward (avc_render_points_fwd_train); neus_full_128.npz: S = 128, per-ray grey background (bg_mode 2)."""
     rec, sd_sdf, sd_col, variance, sdf, col, var, ren, dev = _setup(name)
     bg = rec["bg"].to(dev) if rec["bg"].numel() else None
     out = ren.render(rec["rays_o"].to(dev), rec["rays_d"].to(dev), rec["near"].to(dev), rec["far"].to(dev),
@@ -228,12 +234,17 @@ def test_render_matches_golden_on_reference_z(name):
 
 
 @gpu
-@pytest.mark.parametrize("name", ["neus_small.npz", "neus_full.npz"])
-def test_parameter_gradients_match_golden(name):
+@pytest.mark.parametrize("name", ["neus_small.npz", "neus_full.npz", "neus_full_128.npz"])
+def test_parameter_gradients_match_golden(name, monkeypatch):
     """loss.backward() through the HIP path vs the reference's autograd gradients (incl. the double backward of
-    SDFNetwork.gradient), same scalar loss as oracle/gen_golden.py."""
+    SDFNetwork.gradient), same scalar loss as oracle/gen_golden.py.  neus_full_128.npz: BASELINE config 3's S = 128 through
+    avc_render_points_fwd_train, avc_composite_bwd (bg_mode 2), avc_render_points_bwd and avc_weight_grad_all."""
     from oracle.gen_golden import scalar_loss
     rec, sd_sdf, sd_col, variance, sdf, col, var, ren, dev = _setup(name)
+    if "128" in name:         # 96 rays x 128 samples = 384 blocks in three backward slabs: the slab boundary is part of the case
+        from avatarclip_amd.engine import Engine
+        monkeypatch.setattr(Engine, "SLAB_BLOCKS", 160)
+        assert ren.engine.plan(96, 128)[1] < 96
     bg = rec["bg"].to(dev) if rec["bg"].numel() else None
     out = ren.render(rec["rays_o"].to(dev), rec["rays_d"].to(dev), rec["near"].to(dev), rec["far"].to(dev),
                      background_rgb=bg, cos_anneal_ratio=float(rec["cos_anneal"]), z_vals=rec["z_final"].to(dev))
@@ -396,3 +407,32 @@ def test_grouped_upsample_kernel_equals_one_ray_per_wavefront(n, m, monkeypatch)
     assert torch.equal(zs, za) and torch.equal(torch.gather(za, 1, sla.long()), na)
     keep = torch.ones_like(za, dtype=torch.bool).scatter_(1, sla.long(), False)
     assert torch.equal(sa[keep].reshape(z.shape), sdf)
+
+
+@gpu
+@pytest.mark.parametrize("small,R,S,slab_blocks", [(True, 257, 48, None), (False, 4096, 64, None), (False, 4096, 64, 2048)])
+def test_fused_split_sums_and_unpacking_equal_the_torch_statement(small, R, S, slab_blocks, monkeypatch):
+    """(libavc.so's own case: it had moved into the libavc_ring.so subprocess in round 5.)  avc_weight_grad_reduce + avc_weight_grad_unpack (one launch per slab + one at the end) against the torch statement of the same
+    arithmetic (two reductions + two adds per slab, gather, scale, two index_adds): same products, fp32 sums in a different order;
+    with several slabs the accumulate path is exercised."""
+    from avatarclip_amd.engine import Engine
+    dev = torch.device("cuda")
+    from tests.ring_cases import _inputs, _nets
+    ren = _nets(small, dev)
+    eng = ren.engine
+    if slab_blocks is not None:
+        monkeypatch.setattr(eng, "plan", lambda R_, S_: (R_, slab_blocks * 32 // S_))
+    pk = eng.pack(ren.flat_params())
+    ro, rd, z, dsdf, dn, drgb = _inputs(R, S, dev)
+    gs = []
+    for fused in (False, True):
+        monkeypatch.setattr(Engine, "FUSED_WG_TAIL", fused)
+        _, _, rgbf = eng.points_fwd_train(pk, ro, rd, z, 2 / 32)
+        gs.append(eng.points_bwd(pk, ro, rd, z, 2 / 32, dsdf, dn, drgb, rgbf, panels_valid=True).clone())
+    lay = eng.dl.lay
+    assert torch.isfinite(gs[1]).all()
+    for name, shape in lay.shapes:
+        n = int(np.prod(shape))
+        a, b = (g[lay.pbase[name]:lay.pbase[name] + n] for g in gs)
+        rel = float((a - b).norm() / (a.norm() + 1e-30))
+        assert rel < 2e-6, (name, rel)

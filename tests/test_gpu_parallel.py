@@ -1,4 +1,5 @@
-"""SURVEY.md section 8e parity check on the HIP path: two ranks (gloo collectives, both on GPU 0 -- a development aid, RCCL
+"""SURVEY.md section 8e parity check on the HIP path.  On a node with >= 2 devices: RCCL, one rank per device (the tests below that
+skip themselves on a 1-GPU box).  Everywhere: two / eight ranks (gloo collectives, all on GPU 0 -- a development aid, RCCL
 refuses duplicate devices) each run Runner.train_clip_iteration on their own view; the all-reduced gradient must equal the
 mean of the same two views rendered one after the other by a single process, up to fp32 re-association of the flat bucket."""
 import numpy as np
@@ -64,6 +65,62 @@ def test_bench_spawns_its_own_ranks_and_reports_the_whole_job(world):
         env2 = dict(os.environ); env2.pop("AVC_SINGLE_DEVICE", None); env2.pop("WORLD_SIZE", None); env2.pop("RANK", None)
         r2 = subprocess.run(cmd, env=env2, capture_output=True, text=True, timeout=120, cwd=root)
         assert r2.returncode != 0 and "device" in (r2.stderr + r2.stdout)
+
+
+def _n_devices():
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+@gpu
+@pytest.mark.skipif(_n_devices() < 2, reason="RCCL refuses two ranks on one device: needs a node with >= 2 MI355X (runs by itself on one)")
+def test_rccl_ranks_one_device_each_equal_single_gpu_accumulation(tmp_path):
+    """SURVEY 8e's parity statement on the PRODUCT's layout: world = min(8, devices) ranks, one MI355X each, backend "nccl" = RCCL over
+    xGMI -- broadcast of the weights, per-rank views, ONE all-reduce of the flat gradient bucket (small nets here) -- must give
+    every rank the mean of the gradients ONE process computes for the same views on device 0.  The assertions are the gloo test's;
+    nothing here is specific to a device count, so the first multi-GPU lease produces the evidence without a code change."""
+    import os
+    world = min(8, _n_devices())
+    res, spp = 32, 32
+    mp.spawn(worker, args=(world, free_port(), str(tmp_path), "cuda", res, spp, "nccl"), nprocs=world, join=True)
+    rs = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % k), weights_only=False) for k in range(world)]
+    assert [r["device"] for r in rs] == ["cuda:%d" % k for k in range(world)]
+    assert all(r["backend"] == "nccl" and r["ranks_seen"] == world and r["bucket_is_grad"] for r in rs)
+    assert len({r["data_seed"] for r in rs}) == world
+    a = rs[0]
+    for b in rs:
+        for wa, wb, ga, gb, pa, pb in zip(a["w0"], b["w0"], a["grads"], b["grads"], a["params"], b["params"]):
+            assert torch.equal(wa, wb) and torch.equal(ga, gb) and torch.equal(pa, pb)
+    w0, mean_grads, losses = single_process_accumulation("cuda", world, res, spp, [r["data_seed"] for r in rs])
+    for k in range(world):
+        assert abs(losses[k] - rs[k]["loss"]) < 1e-5, (k, losses, rs[k]["loss"])
+    gn = torch.cat([g.reshape(-1) for g in mean_grads]).norm()
+    for g1, g2 in zip(mean_grads, a["grads"]):
+        assert (g1 - g2).norm() <= 1e-4 * (g1.norm() + 1e-3 * gn)
+    print("RCCL world %d: all-reduced bucket == single-process mean" % world)
+
+
+@gpu
+@pytest.mark.skipif(_n_devices() < 2, reason="needs a node with >= 2 MI355X (runs by itself on one)")
+def test_bench_over_rccl_on_every_device_of_the_node():
+    """`python bench.py --gpus N` on a real node, N = min(8, devices): the line must say that RCCL ran with N ranks on N DIFFERENT
+    devices (`rccl_ranks_seen` and `process_group` come from the process group, not from the flags) and count the rays of all of them."""
+    import json
+    import os
+    import subprocess
+    import sys
+    world = min(8, _n_devices())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "AVC_DIST_BACKEND", "AVC_SINGLE_DEVICE"):
+        env.pop(k, None)
+    env["AVC_ASSERT_DIST"] = "nccl"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "2", "--res", "128", "--small", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == world and out["config"]["collective"] == "nccl (RCCL), %d rank(s)" % world
+    assert out["rccl_ranks_seen"] == world and sorted(out["process_group"]["devices"]) == list(range(world))
+    assert abs(out["value"] - world * 128 * 128 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
 
 
 @gpu
@@ -142,6 +199,7 @@ def test_bench_single_rank_under_the_launcher_runs_the_rccl_path():
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["config"]["collective"] == "nccl (RCCL), 1 rank(s)"
+    assert out["rccl_ranks_seen"] == 1 and out["process_group"] == {"backend": "nccl", "ranks": 1, "devices": [0]}
 
 
 @gpu

@@ -9,16 +9,18 @@ from tests.helpers import load_case, relerr, GOLDEN
 import os
 
 
-@pytest.mark.parametrize("name,has_jitter", [("neus_small.npz", False), ("neus_full.npz", True)])
+@pytest.mark.parametrize("name,has_jitter", [("neus_small.npz", False), ("neus_full.npz", True), ("neus_full_128.npz", True)])
 def test_render_matches_reference(name, has_jitter):
+    """neus_full_128.npz (oracle/gen_golden_128.py): BASELINE config 3's regime -- 64 + 64 samples, steps of 16, per-ray grey background"""
     rec, sd_sdf, sd_col, variance = load_case(name)
+    n0, m = rec["up0_z_in"].shape[1], rec["up0_new_z"].shape[1]
     jitter = rec["jitter"] if has_jitter else None
     bg = rec["bg"] if rec["bg"].numel() else None
     # the up-sampling chain is chaotic in fp32 (1e-7 sdf noise moves inverse-CDF samples), so every step is
     # checked from the reference's own inputs of that step
     for i in range(4):
         z_in, sdf_in = rec["up%d_z_in" % i], rec["up%d_sdf_in" % i]
-        new_z = O.up_sample(rec["rays_o"], rec["rays_d"], z_in, sdf_in, 8, 64 * 2 ** i)
+        new_z = O.up_sample(rec["rays_o"], rec["rays_d"], z_in, sdf_in, m, 64 * 2 ** i)
         assert torch.allclose(new_z, rec["up%d_new_z" % i], atol=1e-6), i
         z2, sdf2 = O.cat_z_vals(sd_sdf, rec["rays_o"], rec["rays_d"], z_in, rec["up%d_new_z" % i], sdf_in, last=(i == 3))
         if i < 3:
@@ -26,10 +28,10 @@ def test_render_matches_reference(name, has_jitter):
             assert torch.allclose(sdf2, rec["up%d_sdf_in" % (i + 1)], atol=5e-6)
         else:
             assert torch.equal(z2, rec["z_final"])
-    z0 = O.coarse_z_vals(rec["near"], rec["far"], 32, jitter)
+    z0 = O.coarse_z_vals(rec["near"], rec["far"], n0, jitter)
     assert torch.allclose(z0, rec["up0_z_in"], atol=1e-6)
     # render on the reference's z so the comparison is not chaotic in z
-    out = O.render(sd_sdf, sd_col, variance, rec["rays_o"], rec["rays_d"], rec["near"], rec["far"],
+    out = O.render(sd_sdf, sd_col, variance, rec["rays_o"], rec["rays_d"], rec["near"], rec["far"], n0, n0,
                    background_rgb=bg, cos_anneal_ratio=float(rec["cos_anneal"]), z_vals=rec["z_final"])
     for k in ("color_fine", "extra_color_fine", "weight_sum", "weight_max", "weights", "mid_z_vals",
               "inside_sphere", "cdf_fine", "s_val"):
@@ -38,7 +40,7 @@ def test_render_matches_reference(name, has_jitter):
     assert abs(out["gradient_error"].item() - rec["out_gradient_error"].item()) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["neus_small.npz", "neus_full.npz"])
+@pytest.mark.parametrize("name", ["neus_small.npz", "neus_full.npz", "neus_full_128.npz"])
 def test_parameter_gradients_match_reference(name):
     from oracle.gen_golden import scalar_loss
     rec, sd_sdf, sd_col, variance = load_case(name)
@@ -53,7 +55,8 @@ def test_parameter_gradients_match_reference(name):
     s, c = req(sd_sdf, "sdf."), req(sd_col, "col.")
     var = variance.clone().requires_grad_(True)
     leaves["var.variance"] = var
-    out = O.render(s, c, var, rec["rays_o"], rec["rays_d"], rec["near"], rec["far"], background_rgb=bg,
+    n0 = rec["up0_z_in"].shape[1]
+    out = O.render(s, c, var, rec["rays_o"], rec["rays_d"], rec["near"], rec["far"], n0, n0, background_rgb=bg,
                    cos_anneal_ratio=float(rec["cos_anneal"]), z_vals=rec["z_final"])
     coef = {k[5:]: v for k, v in rec.items() if k.startswith("coef_")}
     loss = scalar_loss(out, coef)

@@ -3,6 +3,7 @@ mean of the per-rank gradients, and parameters must be identical on every rank a
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -105,6 +106,10 @@ def test_core_slices_follow_the_numa_node_of_each_rank_s_gpu(tmp_path, monkeypat
     # HIP_VISIBLE_DEVICES re-indexes the devices a process sees
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "4,5")
     assert parallel.gpu_numa_nodes(root) == [1, 1]
+    # ... and composes with the runtime-level filter it indexes into (ROCR first): devices 2..7 -> of those, 1 and 3 = physical 3 and 5
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "2,3,4,5,6,7")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1,3")
+    assert parallel.gpu_numa_nodes(root) == [0, 1]
 
 
 def test_queue_oversubscription_is_reported_only_when_ranks_share_a_device(monkeypatch):
@@ -144,4 +149,16 @@ def test_replica_layout_and_environment(tmp_path, monkeypatch):
         assert e["HIP_VISIBLE_DEVICES"] == str(i % 2) and e["RANK"] is None and e["WORLD_SIZE"] is None and e["AVC_REPLICA"] == str(i)
         assert e["GPU_MAX_HW_QUEUES"] == "2"          # 5 processes x 4 queues on one device would oversubscribe it
         assert os.path.exists(str(tmp_path / "logs" / ("replica_%d.log" % i)))
+    # a restricted parent (a scheduler's HIP_VISIBLE_DEVICES=2,3 / ROCR_VISIBLE_DEVICES=4,5,6,7): replica ordinals are relative to the
+    # parent's visible set, so the children get the parent's entries, and the runtime-level filter stays in place
+    assert replicas.child_visibility(1, {"HIP_VISIBLE_DEVICES": "2,3"}) == ({"HIP_VISIBLE_DEVICES": "3"}, ("CUDA_VISIBLE_DEVICES",))
+    assert replicas.child_visibility(0, {"CUDA_VISIBLE_DEVICES": "5, 6"})[0] == {"HIP_VISIBLE_DEVICES": "5"}
+    assert replicas.child_visibility(2, {"ROCR_VISIBLE_DEVICES": "4,5,6,7"})[0] == {"HIP_VISIBLE_DEVICES": "2"}
+    with pytest.raises(ValueError):
+        replicas.child_visibility(2, {"HIP_VISIBLE_DEVICES": "2,3"})
+    prog2 = "import os, json, sys; json.dump({k: os.environ.get(k) for k in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES')}, open(sys.argv[1], 'w'))"
+    cmds = [[sys.executable, "-c", prog2, outs[i]] for i in range(2)]
+    assert replicas.launch_commands(cmds, gpus=[0, 1], env=dict(os.environ, ROCR_VISIBLE_DEVICES="4,5,6,7", HIP_VISIBLE_DEVICES="2,3", CUDA_VISIBLE_DEVICES="2,3")) == [0, 0]
+    for i in range(2):
+        assert json.load(open(outs[i])) == {"HIP_VISIBLE_DEVICES": str(2 + i), "ROCR_VISIBLE_DEVICES": "4,5,6,7", "CUDA_VISIBLE_DEVICES": None}
     assert replicas.main(["--confs", "/nonexistent/a.conf", "--gpus", "0", "--log_dir", str(tmp_path / "l2"), "--mode", "train"]) == 1

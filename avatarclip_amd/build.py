@@ -16,6 +16,11 @@ SOURCES = ["avc_core.hip", "avc_mlp_fwd.hip", "avc_mlp_bwd.hip", "avc_wgrad.hip"
 HEADERS = ["avc_common.h", "avc_stage.h", "avc_mlp.h", "avc_bwd_body.h", "avc_wgrad_body.h", "avc_offsets_gen.h", os.path.join("..", "..", "include", "avc.h"),
            os.path.join("..", "..", "include", "avc_ring.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"] + os.environ.get("AVC_EXTRA_FLAGS", "").split()
+# avc_mlp_fwd.hip holds the one kernel built for ONE wavefront per SIMD on the 512-entry unified register file (mlp_sdf2_kernel, 256-thread
+# workgroups): hipcc then picks the AGPR form of the MFMAs (accumulators in the accumulation half, one v_accvgpr_read per element in front of
+# every epilogue).  The VGPR form keeps the accumulators where the epilogues read them; the kernel puts the ACTIVATIONS into AGPRs itself.
+# Every other kernel of that file has 512+ threads per workgroup and uses no AGPRs either way (identical code with and without the flag).
+SOURCE_FLAGS = {"avc_mlp_fwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc():
@@ -55,7 +60,7 @@ def build(force: bool = False, verbose: bool = False, ring: bool = False) -> str
         obj = os.path.join(CSRC, s.replace(".hip", os.environ.get("AVC_OBJ_SUFFIX", "") + ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([_hipcc()] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([_hipcc()] + FLAGS + SOURCE_FLAGS.get(s, []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -590,3 +590,150 @@ __device__ __forceinline__ float sdf_only(ST& sg, const h8* __restrict__ Wf, TP 
   ), NoHook{}, TabBias{T + o.v[OFF_BS], h});
   return xhalf_sum(part) + T[o.v[OFF_BL0]];
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Two 32-point groups per wavefront (round 6): the structural terms of the one-group engine -- one LDS A fragment
+// per MFMA, one group barrier per 4 weight tiles per 32 points, 392 KiB of weight DMA per workgroup round -- are per WAVEFRONT, not per
+// point.  A wavefront that owns 64 points feeds every A fragment to TWO MFMAs (independent accumulators, so a filler between them
+// never breaks a back-to-back accumulate path), at twice the register state: ~380 live registers, i.e. one wavefront per SIMD on the
+// 512-entry unified file (MFMA takes its B operands from either half).
+// ---------------------------------------------------------------------------------------------------------------
+#define AVC_EPI2(...) [&](int t, int q, const facc& acc) __attribute__((always_inline)) { __VA_ARGS__ }
+#ifndef AVC_LDS_AHEAD_M2
+#define AVC_LDS_AHEAD_M2 8   // A fragments in flight ahead of the MFMA pairs
+#endif
+// the epilogues of two groups (2 x 16 elements: exp, add, log, med3 + 8 conversions = ~150 instructions, 64 of them transcendental)
+// dealt over the 2 KS MFMAs of the next tile: with ONE wavefront per SIMD about five single-issue instructions fit the 32-cycle shadow of
+// an MFMA (MI355X_MICROARCH.md, per-instruction constants), which is what a 256-wide layer offers (32 MFMAs per tile step)
+#ifndef AVC_M2_TRANS_PER_MFMA
+#define AVC_M2_TRANS_PER_MFMA 2
+#endif
+#ifndef AVC_M2_VALU_PER_MFMA
+#define AVC_M2_VALU_PER_MFMA 3
+#endif
+template <int NM>
+__device__ __forceinline__ void interleave_m2() {
+  constexpr int scale = NM >= 32 ? 1 : (32 + NM - 1) / NM;   // short chains (layer 0: 6 MFMAs) take the whole epilogue between them
+#pragma unroll
+  for (int k = 0; k < NM; ++k) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x400, AVC_M2_TRANS_PER_MFMA * scale, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, AVC_M2_VALU_PER_MFMA * scale, 0);
+  }
+}
+template <typename V, int KS, class ST, class B>
+__device__ __forceinline__ void tile_mma_m2(const ST& st, int j, const V (&in0)[KS], const V (&in1)[KS], facc& acc0, facc& acc1,
+                                            const B& bias, int t) {
+  const V* a_lds = reinterpret_cast<const V*>(st.lds + st.par * ST::BUF_BYTES + j * KS * 1024) + st.lane;
+  if constexpr (B::on) {   // the tile's bias row enters through both accumulators (read twice: an LDS read is cheaper than 16 moves)
+    float b0[16], b1[16];
+    load16(bias.tab, t, bias.h, b0);
+    load16(bias.tab, t, bias.h, b1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = b0[r]; acc1[r] = b1[r]; }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  }
+  V a[KS];
+#pragma unroll
+  for (int s = 0; s < KS && s < AVC_LDS_AHEAD_M2; ++s) a[s] = a_lds[s * 64];
+#pragma unroll
+  for (int s = 0; s < KS; s += 2) {
+    if (s + 1 < KS) asm("" : "+v"(a[s]), "+v"(a[s + 1]));
+#pragma unroll
+    for (int k = s + AVC_LDS_AHEAD_M2; k < s + AVC_LDS_AHEAD_M2 + 2 && k < KS; ++k) a[k] = a_lds[k * 64];
+#pragma unroll
+    for (int k = s; k < s + 2 && k < KS; ++k) {
+      acc0 = MF<V>::mma(a[k], in0[k], acc0);
+      acc1 = MF<V>::mma(a[k], in1[k], acc1);
+    }
+  }
+}
+template <typename V, int KS, int NT, class ST, typename Epi, class Bias = NoBias>
+__device__ __forceinline__ void layer_m2(ST& st, const V* __restrict__ blob, int offw, const Next& after, const V (&in0)[KS],
+                                         const V (&in1)[KS], Epi&& epi, const Bias& bias = NoBias{}) {
+  constexpr int G = ST::template group<KS>();
+  constexpr int NG = (NT + G - 1) / G;
+  facc prev0, prev1;
+  int tp = -1;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    AVC_SYNC();
+    if (g + 1 < NG) {
+      Next n;
+      n.ptr = blob + (offw >> 3) + (long)((g + 1) * G * KS) * 64;
+      n.chunks = KS * ((NT - (g + 1) * G) < G ? (NT - (g + 1) * G) : G);
+      stage_issue(st, n, st.par ^ 1);
+    } else {
+      stage_issue(st, after, st.par ^ 1);
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const int t = g * G + j;
+      if (t < NT) {
+        facc a0, a1;
+        tile_mma_m2<V, KS>(st, j, in0, in1, a0, a1, bias, t);
+        if (tp >= 0) {
+          epi(tp, 0, prev0);
+          epi(tp, 1, prev1);
+          interleave_m2<2 * KS>();
+        }
+        prev0 = a0;
+        prev1 = a1;
+        tp = t;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    st.par ^= 1;
+  }
+  epi(tp, 0, prev0);
+  epi(tp, 1, prev1);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// SDF value of two 32-point groups (x[q] = this lane's point of group q): the layers of sdf_only, every A fragment used twice
+template <class N, class ST, typename TP>
+__device__ __forceinline__ void sdf_only2(ST& sg, const h8* __restrict__ Wf, TP T, const AvcOffsets& o, int h, const float (&x)[2][3],
+                                          float (&out)[2]) {
+  float part[2] = {0.f, 0.f};
+  h8 pef[2][3];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    PE pe;
+    pe_compute(x[q], h, pe);
+    const auto wpe = T + o.v[OFF_WL0_PE] + h * 24;
+#pragma unroll
+    for (int k = 0; k < 24; ++k) part[q] += wpe[k] * pe.v[k];
+    asm volatile("" : "+v"(part[q]));
+    pe_to_frags_f16(pe, x[q], h, pef[q]);
+  }
+  // the activations live in the ACCUMULATION half of the unified register file from the moment they exist ("a" constraint: 8 v_accvgpr_write
+  // per tile and group); the MFMAs take them from there as B operands, and the 256 architectural VGPRs stay free for the accumulators, the
+  // A fragments and the epilogues' temporaries -- left to itself hipcc keeps ~180 of the 256 activation registers in VGPRs and then serialises
+  // every softplus through one temporary (exp -> add -> log -> med3, dependent, with nobody else on the SIMD to fill the latencies)
+#define AVC_M2_ACT(OUT) AVC_EPI2(float a[16]; softplus2_tile(acc, a);                                                          \
+                                 h8 f0, f1;                                                                                   \
+                                 _Pragma("unroll") for (int j = 0; j < 8; ++j) { f0[j] = (_Float16)a[j]; f1[j] = (_Float16)a[8 + j]; } \
+                                 asm volatile("" : "+a"(f0), "+a"(f1));                                                       \
+                                 OUT[q][2 * t] = f0; OUT[q][2 * t + 1] = f1;)
+  h8 hlast[2][N::HK];
+  {
+    h8 h1[2][N::HK];
+    layer_m2<h8, 3, N::HT>(sg, Wf, o.v[OFF_W0], nxt<N, OFF_WM0>(sg, Wf, o), pef[0], pef[1], AVC_M2_ACT(h1), TabBias{T + o.v[OFF_B0], h});
+    if constexpr (N::NMID == 2) {
+      h8 hm0[2][N::HK];
+      layer_m2<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WM1>(sg, Wf, o), h1[0], h1[1], AVC_M2_ACT(hm0), TabBias{T + o.v[OFF_BM0], h});
+      layer_m2<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM1], nxt<N, OFF_WS>(sg, Wf, o), hm0[0], hm0[1], AVC_M2_ACT(hlast), TabBias{T + o.v[OFF_BM1], h});
+    } else {
+      layer_m2<h8, N::HK, N::HT>(sg, Wf, o.v[OFF_WM0], nxt<N, OFF_WS>(sg, Wf, o), h1[0], h1[1], AVC_M2_ACT(hlast), TabBias{T + o.v[OFF_BM0], h});
+    }
+  }
+  layer_m2<h8, N::HK, N::ST>(sg, Wf, o.v[OFF_WS], no_next(), hlast[0], hlast[1], AVC_EPI2(
+    float w[16];
+    load16(T + o.v[OFF_WL0_ACC], t, h, w);
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) part[q] += w[r] * softplus2(acc[r]);
+  ), TabBias{T + o.v[OFF_BS], h});
+#pragma unroll
+  for (int q = 0; q < 2; ++q) out[q] = xhalf_sum(part[q]) + T[o.v[OFF_BL0]];
+}

@@ -47,6 +47,10 @@ constexpr bool ABL_NOMISC = true;
 constexpr bool ABL_NOMISC = false;
 #endif
 #include "../../include/avc.h"
+#include <stdlib.h>
+#ifndef AVC_SDF_PPW_DEFAULT
+#define AVC_SDF_PPW_DEFAULT 32   // points per wavefront of avc_sdf_forward: 32 (mlp_sdf_kernel) | 64 (mlp_sdf2_kernel)
+#endif
 
 template <class N>
 __global__ __launch_bounds__(64 * SDF_WPB) void mlp_sdf_kernel(PointSrc ps, long npts, const h8* __restrict__ Wf,
@@ -79,6 +83,46 @@ __global__ __launch_bounds__(64 * SDF_WPB) void mlp_sdf_kernel(PointSrc ps, long
   }
   const float sdfv = sdf_only<N>(sg, Wf, Tl, o, h, x0);
   if (valid && h == 0) sdf_out[oi] = sdfv;
+}
+
+
+// ---- the same with two 32-point groups per wavefront (sdf_only2, avc_mlp.h): 4-wave workgroups, one wavefront per SIMD on the
+// ---- 512-entry unified register file; every staged weight tile serves 256 points and every LDS A fragment two MFMAs
+#ifndef SDF2_WPB
+#define SDF2_WPB 4
+#endif
+template <class N>
+__global__ __launch_bounds__(64 * SDF2_WPB) void mlp_sdf2_kernel(PointSrc ps, long npts, const h8* __restrict__ Wf,
+                                                                 const float* __restrict__ T, float* __restrict__ sdf_out,
+                                                                 const int* __restrict__ slot, int ld_out) {
+  constexpr AvcOffsets o = Off<N>::value;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  typedef StageT<FWD_G> ST;
+  const int lane = threadIdx.x & 63;
+  const int h = lane >> 5;
+  const int p = lane & 31;
+  const long blk = 2 * ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));   // this wavefront's blocks: blk, blk + 1
+  ST sg = stage_init<ST::G>(lds);
+  stage_issue(sg, nxt<N, OFF_W0>(sg, Wf, o), 0);
+  const lds_tab_t Tl = tab_to_lds(lds + ST::LDS_BYTES, T, o.v[OFF_TAB_END]);
+  __syncthreads();
+  float x[2][3];
+  long oi[2];
+  bool valid[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    long i = (blk + q) * 32 + p;
+    valid[q] = i < npts;
+    if (!valid[q]) i = npts - 1;
+    fetch_point(ps, i, x[q]);
+    oi[q] = i;
+    if (slot) oi[q] = (i / ps.S) * ld_out + slot[i];
+  }
+  float sdfv[2];
+  sdf_only2<N>(sg, Wf, Tl, o, h, x, sdfv);
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+    if (valid[q] && h == 0) sdf_out[oi[q]] = sdfv[q];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -363,14 +407,27 @@ static int launch_sdf(int net, PointSrc ps, long npts, const void* wf, const flo
     return 1;
   }
   hipStream_t s = (hipStream_t)stream;
-  const int wpb = SDF_WPB;   // wavefronts per workgroup
-  const int grid = grid_for(npts, wpb, 0x7fffffff);
   const int lds_bytes = StageT<FWD_G>::LDS_BYTES + AVC_TAB_LDS_BYTES;
   static unsigned long long attr_seen = 0;
   if (avc_first_use_on_device(attr_seen)) {
     hipFuncSetAttribute((const void*)mlp_sdf_kernel<NetFull>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     hipFuncSetAttribute((const void*)mlp_sdf_kernel<NetSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipFuncSetAttribute((const void*)mlp_sdf2_kernel<NetFull>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipFuncSetAttribute((const void*)mlp_sdf2_kernel<NetSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   }
+  // AVC_SDF_POINTS_PER_WAVE=64: the two-group kernel (A/B partner: profiles/r06_ab_kernels.txt); read once per process
+  static const int ppw = [] { const char* e = getenv("AVC_SDF_POINTS_PER_WAVE"); return e ? atoi(e) : AVC_SDF_PPW_DEFAULT; }();
+  if (ppw == 64) {
+    const int grid2 = grid_for(npts, 2 * SDF2_WPB, 0x7fffffff);
+    if (net == AVC_NET_FULL)
+      hipLaunchKernelGGL((mlp_sdf2_kernel<NetFull>), dim3(grid2), dim3(64 * SDF2_WPB), lds_bytes, s, ps, npts, (const h8*)wf, tab, sdf_out, slot, ld_out);
+    else if (net == AVC_NET_SMALL)
+      hipLaunchKernelGGL((mlp_sdf2_kernel<NetSmall>), dim3(grid2), dim3(64 * SDF2_WPB), lds_bytes, s, ps, npts, (const h8*)wf, tab, sdf_out, slot, ld_out);
+    else { avc_set_error("unknown net id"); return 1; }
+    return avc_check_launch("avc_sdf_forward");
+  }
+  const int wpb = SDF_WPB;   // wavefronts per workgroup
+  const int grid = grid_for(npts, wpb, 0x7fffffff);
   if (net == AVC_NET_FULL)
     hipLaunchKernelGGL((mlp_sdf_kernel<NetFull>), dim3(grid), dim3(64 * wpb), lds_bytes, s, ps, npts, (const h8*)wf, tab,
                        sdf_out, slot, ld_out);

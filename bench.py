@@ -120,53 +120,91 @@ model {
     return ConfigFactory.parse_string(text)
 
 
-def cpu_baseline(spp, rays=4096, iters=2, max_threads=16):
-    """The CPU oracle (port of the reference's algorithm, oracle/neus_oracle.py + clip_vit_oracle.py) on a bounded
-    sample of the same workload: `rays` rays of one view (64x64 = BASELINE config 1's view), full-size nets, full step incl.
-    2 CLIP passes and Adam; 1 warm-up + `iters` timed iterations (about 20 s of CPU work)."""
-    from oracle import neus_oracle as O, clip_vit_oracle as C
-    from avatarclip_amd import fields
-    # a bounded number of host threads: the many small ops of the reference path oversubscribe badly beyond ~16 threads
-    # (measured: 256 threads on the GPU box's host = 286 s/iter for 1024 rays vs 4 s with 8 threads)
-    nthreads = max(1, min(max_threads, os.cpu_count() or 1))
-    torch.set_num_threads(nthreads)
+def cpu_baseline(spp, threads=(8, 16, 32)):
+    """the reference's step on the host CPUs, in the same run, as a REPORTED number.  When the reference tree
+    is present (the build container; $AVATARCLIP_REFERENCE or /root/reference) its OWN modules are timed -- models/fields.py and
+    models/renderer.py imported unmodified through oracle/ref_loader.py (`kind: "reference"`); a GPU box never holds that tree, so
+    there the CPU oracle is timed (oracle/neus_oracle.py, pinned to the reference's outputs by tests/golden: `kind: "port"`).  Either
+    way the step is the whole iteration: NeuS render of full-size nets -> shading -> 2 CLIP ViT-B/32 passes (oracle/clip_vit_oracle.py:
+    OpenAI's package is not installable offline) -> losses -> backward -> Adam.
+    Bounded (~1 min): a 3-point thread sweep on a 64 x 64 view (4 096 rays: 1 warm-up + 1 timed iteration per thread count, the best
+    count stated and used from there on), one more timed 64 x 64 iteration, and ONE chunk of a 224 x 224 view (6 272 of its 50 176
+    rays: the autograd graph of the whole view does not fit a 64 GB host, profiles/r06_cpu_reference_vs_port.md runs all 8 chunks)."""
+    from oracle import neus_oracle as O, clip_vit_oracle as C, ref_loader
+    use_ref = ref_loader.reference_available()
+    host = os.cpu_count() or 1
     torch.manual_seed(0)
-    sdf = fields.SDFNetwork(d_out=257, d_in=3, d_hidden=256, n_layers=4, skip_in=[4], multires=6)
-    col = fields.RenderingNetwork(d_feature=256, mode="no_view_dir", d_in=6, d_out=3, d_hidden=256, n_layers=2, extra_color=True)
-    var = torch.nn.Parameter(torch.tensor(0.3))
-    params = list(sdf.parameters()) + list(col.parameters()) + [var]
+    if use_ref:
+        RF = ref_loader.load_reference()
+        sdf, col = RF.SDFNetwork(**ref_loader.FULL_SDF), RF.RenderingNetwork(**ref_loader.FULL_COLOR)
+        var_net = RF.SingleVarianceNetwork(0.3)
+        ren = RF.NeuSRenderer(None, sdf, var_net, col, spp // 2, spp // 2, 0, 4, 1.0, extra_color=True)
+        params = list(sdf.parameters()) + list(var_net.parameters()) + list(col.parameters())
+    else:
+        from avatarclip_amd import fields
+        sdf = fields.SDFNetwork(d_out=257, d_in=3, d_hidden=256, n_layers=4, skip_in=[4], multires=6)
+        col = fields.RenderingNetwork(d_feature=256, mode="no_view_dir", d_in=6, d_out=3, d_hidden=256, n_layers=2, extra_color=True)
+        var = torch.nn.Parameter(torch.tensor(0.3))
+        params = list(sdf.parameters()) + [var] + list(col.parameters())
     opt = torch.optim.Adam(params, lr=5e-4)
     clip_sd = C.random_state_dict(0)
     text = torch.nn.functional.normalize(torch.randn(1, 512, generator=torch.Generator().manual_seed(11)), dim=-1)
-    side = int(round(rays ** 0.5))
-    pose = torch.from_numpy(O.lookat(np.array([0.3, 0.2, 1.5]), np.zeros(3), np.array([0., 1, 0]))).float()
-    o, v = O.gen_rays_pose(pose, side, side, 0.5 * side / np.tan(np.pi / 6))
-    ro, rd = o.reshape(-1, 3).contiguous(), v.reshape(-1, 3).contiguous()
-    near, far = O.near_far_from_sphere(ro, rd)
-    R = ro.shape[0]
-    times = []
-    for it in range(iters + 1):
+
+    def view(side):
+        pose = torch.from_numpy(O.lookat(np.array([0.3, 0.2, 1.5]), np.zeros(3), np.array([0., 1, 0]))).float()
+        o, v = O.gen_rays_pose(pose, side, side, 0.5 * side / np.tan(np.pi / 6))
+        ro, rd = o.reshape(-1, 3).contiguous(), v.reshape(-1, 3).contiguous()
+        return (ro, rd) + tuple(O.near_far_from_sphere(ro, rd))
+
+    def step(ro, rd, near, far, side, rows):
+        """one iteration on `rows` image rows of a side x side view (all rows: the whole step; fewer: one gradient-accumulation chunk,
+        with the CLIP passes run on the chunk's rows pasted into a black frame)"""
         t0 = time.time()
-        sd_s, sd_c = dict(sdf.named_parameters()), dict(col.named_parameters())
-        jitter = torch.rand(R, 1)
-        out = O.render(sd_s, sd_c, var, ro, rd, near, far, spp // 2, spp // 2, 4, jitter, torch.zeros(1, 3), 1.0)
+        n = rows * side
+        ro, rd, near, far = ro[:n], rd[:n], near[:n], far[:n]
+        if use_ref:
+            out = ren.render(ro, rd, near, far, background_rgb=torch.zeros(1, 3), cos_anneal_ratio=1.0)      # renderer.py:302-397 itself
+        else:
+            out = O.render(dict(sdf.named_parameters()), dict(col.named_parameters()), var, ro, rd, near, far, spp // 2, spp // 2, 4,
+                           torch.rand(n, 1), torch.zeros(1, 3), 1.0)
         tex, shade = O.cast_light(out, np.array([0.3, 0.5, 0.8]), 0.1)
-        loss, _, _, _ = O.neus_losses(out, torch.zeros(R, 3), torch.ones(R, 1), 0.1, 1.0)
+        loss, _, _, _ = O.neus_losses(out, torch.zeros(n, 3), torch.ones(n, 1), 0.1, 1.0)
         for img in (tex, shade):
-            enc = C.encode_image(clip_sd, O.clip_preprocess(img.reshape(side, side, 3)))
+            frame = torch.cat([img.reshape(rows, side, 3), torch.zeros(side - rows, side, 3)], 0) if rows < side else img.reshape(side, side, 3)
+            enc = C.encode_image(clip_sd, O.clip_preprocess(frame))
             loss = loss + (1.0 - O.clip_cosine(enc, text))
         opt.zero_grad()
         loss.backward()
         opt.step()
-        times.append(time.time() - t0)
-        if times[-1] > 60.0:   # keep the default bench run within minutes even on a slow host
+        return time.time() - t0
+
+    v64 = view(64)
+    sweep = {}
+    for nt in threads:
+        if nt > host and sweep:
+            continue
+        torch.set_num_threads(min(nt, host))
+        step(*v64, 64, 64)                      # warm-up at this thread count
+        sweep[min(nt, host)] = step(*v64, 64, 64)
+        if sweep[min(nt, host)] > 60.0:         # a slow host: keep the default bench run within minutes
             break
-    t = float(np.mean(times[1:])) if len(times) > 1 else float(times[0])
-    return {"value": R / t, "unit": "rays/s", "cores": nthreads, "host_cores": os.cpu_count(), "kind": "port",
-            "sample": "%d rays (%dx%d view) x %d spp, full nets, full step incl. 2 CLIP passes + Adam, %d timed iters, %.2f s/iter"
-                      % (R, side, side, spp, max(len(times) - 1, 1), t),
-            # the reference's OWN modules beside this port, at 64^2 and 224^2 rays (needs /root/reference: build container only)
-            "reference_vs_port_table": "profiles/r02_cpu_reference_vs_port.md"}
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    t64 = 0.5 * (sweep[best] + step(*v64, 64, 64))
+    res = {"value": 4096 / t64, "unit": "rays/s", "cores": best, "host_cores": host, "kind": "reference" if use_ref else "port",
+           "sample": "64x64 view (4 096 rays) x %d spp, full-size nets, whole step incl. 2 CLIP ViT-B/32 passes + Adam, 2 timed iterations at the "
+                     "best of the thread counts tried: %.2f s/iter" % (spp, t64),
+           "thread_sweep_s_per_iter": {str(k): round(v, 3) for k, v in sweep.items()},
+           "iters_per_sec_64x64": 1.0 / t64}
+    if t64 < 30.0:
+        v224 = view(224)
+        t224 = step(*v224, 224, 28)
+        res["sample_224"] = {"value": 28 * 224 / t224, "unit": "rays/s", "rays": 28 * 224,
+                             "sample": "224x224 view (BASELINE config 2), rows 0-27 of 224 = chunk 1 of the 8 its autograd graph has to be cut "
+                                       "into on a 64 GB host, 1 timed iteration: %.2f s" % t224,
+                             "whole_view_s_per_iter_extrapolated": 8 * t224}
+    res["reference_vs_port_table"] = "profiles/r06_cpu_reference_vs_port.md"
+    return res
 
 
 def load_pmc():

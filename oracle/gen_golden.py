@@ -85,7 +85,9 @@ def scalar_loss(out, coef):
 
 
 def run_case(R, sdf_net, col_net, var_net, n_samples, n_importance, steps, rays_o, rays_d, near, far, jitter,
-             bg, cos_anneal, seed):
+             bg, cos_anneal, seed, coherent=False):
+    """coherent = False: independent random loss coefficients per ray (neus_small / neus_full); True: the SAME coefficients on every
+    ray and the mask target taken from the render itself -- one sign per term, as every loss of main.py:489-534 has"""
     ren = R.NeuSRenderer(None, sdf_net, var_net, col_net, n_samples=n_samples, n_importance=n_importance,
                          n_outside=0, up_sample_steps=steps, perturb=1.0 if jitter is not None else 0.0,
                          extra_color=True)
@@ -104,6 +106,9 @@ def run_case(R, sdf_net, col_net, var_net, n_samples, n_importance, steps, rays_
     Rn = rays_o.shape[0]
     coef = dict(c1=torch.randn(Rn, 3, generator=g) * 0.1, c2=torch.randn(Rn, 3, generator=g) * 0.1,
                 c3=torch.randn(Rn, 3, generator=g) * 0.1, mask=(torch.rand(Rn, 1, generator=g) > 0.5).float())
+    if coherent:
+        coef = dict(c1=torch.tensor([[0.07, -0.04, 0.05]]).expand(Rn, 3).contiguous(), c2=torch.tensor([[-0.03, 0.08, 0.06]]).expand(Rn, 3).contiguous(),
+                    c3=torch.tensor([[0.02, -0.03, 0.025]]).expand(Rn, 3).contiguous(), mask=(out["weight_sum"].detach() > 0.5).float())
     loss = scalar_loss(out, coef)
     params = [p for net in (sdf_net, var_net, col_net) for p in net.parameters()]
     names = [pfx + n for pfx, net in (("sdf.", sdf_net), ("var.", var_net), ("col.", col_net))

@@ -7,6 +7,8 @@ tests/golden/neus_full_128.npz: the full-size nets of neus_full.npz (the weights
 of renderer.py:277-281) -- per-step intermediates of the reference's up_sample / cat_z_vals at n = 64, 80, 96, 112 with m = 16
 (renderer.py:133-193, 39-69), the outputs of NeuSRenderer.render at S = 128 (renderer.py:195-300) and the reference's autograd
 gradients of gen_golden.scalar_loss for every parameter, including the double backward of SDFNetwork.gradient (fields.py:96-107).
+The loss coefficients are the SAME on every ray (run_case(coherent=True): one sign per term, as the losses of main.py:489-534 have), so the
+1e-2 gate of SURVEY 8d applies to EVERY tensor without the carve-out the random-coefficient fixtures need (profiles/r05_gradient_noise.md).
 """
 import os
 import sys
@@ -56,7 +58,7 @@ def main():
     NR = len(sel)
     jitter = torch.rand(NR, 1, generator=torch.Generator().manual_seed(22))
     bg = torch.rand(NR, 1, generator=torch.Generator().manual_seed(23))
-    rec = run_case(R, sdf, col, var, 64, 64, 4, ro[sel], rd[sel], near[sel], far[sel], jitter, bg, 0.6, seed=24)
+    rec = run_case(R, sdf, col, var, 64, 64, 4, ro[sel], rd[sel], near[sel], far[sel], jitter, bg, 0.6, seed=24, coherent=True)
     rec["ray_index"] = sel.numpy()
     assert rec["z_final"].shape == (NR, 128) and rec["up3_z_in"].shape == (NR, 112) and rec["up0_new_z"].shape == (NR, 16)
     np.savez_compressed(os.path.join(GOLD, "neus_full_128.npz"), **rec)

@@ -2,14 +2,15 @@
 imported unmodified through oracle/ref_loader.py) against the CPU port (oracle/neus_oracle.py) on the same rays, weights and
 jitter: one NeuS render + loss + backward + Adam step of the full-size networks at 64 x 64 and 224 x 224 rays, 64 spp.
 (The CLIP term is left out on both sides: the `clip` package is absent; it is <= 0.3 % of the work)
-    python scripts/cpu_ref_vs_port.py > profiles/r02_cpu_reference_vs_port.md"""
+Round 6: a thread sweep at 64 x 64 (AVC_CPU_THREADS = comma list, default 8,16,32 clipped to the host's cores), the 224 x 224 view at the
+best count.     python scripts/cpu_ref_vs_port.py > profiles/r06_cpu_reference_vs_port.md"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import neus_oracle as O, ref_loader
 
-nthreads = int(os.environ.get("AVC_CPU_THREADS", os.cpu_count() or 1))
-torch.set_num_threads(nthreads)
+host = os.cpu_count() or 1
+sweep = sorted({min(int(t), host) for t in os.environ.get("AVC_CPU_THREADS", "8,16,32").split(",")})
 R = ref_loader.load_reference()
 
 
@@ -37,12 +38,16 @@ def loss_of(out, Rn):
     return l + out["extra_color_fine"].mean()
 
 
+print("host cores: %d; thread counts tried at 64 x 64: %s; torch %s\n" % (host, sweep, torch.__version__))
 print("| rays | leg | s / iteration | rays/s | threads | loss |")
 print("|---|---|---|---|---|---|")
-for side, iters in ((64, 2), (224, 1)):
+best = {}
+for side, iters, nthreads in [(64, 2, t) for t in sweep] + [(224, 1, None)]:
     ro, rd, near, far = rays(side)
     Rn = ro.shape[0]
     for leg in ("reference modules", "port (oracle/neus_oracle.py)"):
+        nt = nthreads if nthreads is not None else min(best[leg], key=best[leg].get)
+        torch.set_num_threads(nt)
         sdf, col, var = build()
         params = list(sdf.parameters()) + list(var.parameters()) + list(col.parameters())
         opt = torch.optim.Adam(params, lr=5e-4)
@@ -69,4 +74,6 @@ for side, iters in ((64, 2), (224, 1)):
             opt.step()
             ts.append(time.time() - t0)
         t = float(np.mean(ts[1:])) if len(ts) > 1 else ts[0]
-        print("| %d (%dx%d) | %s | %.2f | %.0f | %d | %.6f |" % (Rn, side, side, leg, t, Rn / t, nthreads, loss.item()), flush=True)
+        if side == 64:
+            best.setdefault(leg, {})[nt] = t
+        print("| %d (%dx%d) | %s | %.2f | %.0f | %d | %.6f |" % (Rn, side, side, leg, t, Rn / t, nt, loss.item()), flush=True)

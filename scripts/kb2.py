@@ -6,6 +6,8 @@ from avatarclip_amd.engine import Engine
 dev = torch.device("cuda"); torch.manual_seed(0)
 if os.environ.get("KB_MAX_FWD_WAVES"):   # a variant built with -DFWD_WPB=w needs 256 x w (one workgroup per CU)
     Engine.MAX_FWD_WAVES = int(os.environ["KB_MAX_FWD_WAVES"])
+if os.environ.get("KB_MAX_BWD_WAVES"):   # likewise -DBWD_WPB=w
+    Engine.MAX_BWD_WAVES = int(os.environ["KB_MAX_BWD_WAVES"])
 sdf = fields.SDFNetwork(d_out=257, d_in=3, d_hidden=256, n_layers=4, skip_in=[4], multires=6).to(dev)
 col = fields.RenderingNetwork(d_feature=256, mode="no_view_dir", d_in=6, d_out=3, d_hidden=256, n_layers=2, extra_color=True).to(dev)
 var = fields.SingleVarianceNetwork(0.3).to(dev)

@@ -75,7 +75,11 @@ def test_300_iterations_track_the_independent_oracle():
         a.update_learning_rate()
     loss_hip = torch.stack(loss_hip).cpu().double().numpy()
     assert np.isfinite(loss_hip).all()
-    # ---------------- oracle leg (CPU)
+    # ---------------- oracle leg (CPU).  A bounded thread count: on the GPU box's 256 host cores torch's default oversubscribes the many small
+    # ops of this path (11 min for the 300 iterations with the default, ~2 min with 16 threads)
+    import os
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
     loss_or = []
     for i in range(N_ITERS):
         eye, at, theta, phi, is_front = cams[i]
@@ -86,6 +90,7 @@ def test_300_iterations_track_the_independent_oracle():
                       light_dir=light, ambience=amb)
         loss_or.append(float(IT.train_clip_iteration(st, oconf, dr, clip_sd, texts, i)["loss"]))
     loss_or = np.asarray(loss_or)
+    torch.set_num_threads(nthreads)
     assert abs(a.optimizer.param_groups[0]["lr"] - st.opt.param_groups[0]["lr"]) < 1e-12 and a.iter_step == st.iter_step == N_ITERS
     # ---------------- the curves
     print("iter   hip      oracle   (single iterations)")

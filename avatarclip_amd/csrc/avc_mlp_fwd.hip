@@ -139,6 +139,12 @@ __global__ __launch_bounds__(64 * SDF2_WPB) void mlp_sdf2_kernel(PointSrc ps, lo
 //                  (non-temporal) and ride under a kernel that is bound by its matrix / vector work.
 // Persistent workgroups.  Plain (temporal) accesses for the tiles that are re-read within the same block.
 // ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ FragPair<h8> fwd_abl_pair(int t) {   // (AVC_ABL_FWD_NORR: an opaque constant in place of a tile read back)
+  FragPair<h8> d;
+  _Pragma("unroll") for (int j = 0; j < 8; ++j) { d.a0[j] = (_Float16)(0.25f + 0.01f * t); d.a1[j] = (_Float16)(0.5f - 0.01f * t); }
+  asm volatile("" : "+v"(d.a0), "+v"(d.a1));
+  return d;
+}
 template <typename P> __device__ __forceinline__ P launder_ptr(P p) {
   asm volatile("" : "+s"(p));
   return p;
@@ -262,8 +268,14 @@ __global__ __launch_bounds__(64 * FWD_WPB) void mlp_render_kernel(PointSrc ps, l
     // ---------------------------------------------------------------- normal sweep: g_h(prev) = W^T g_a ; g_a(prev) = g_h sigma(h_prev)
     float n[3];
     {
+#ifdef AVC_ABL_FWD_NORR   // timing ablation only (garbage results): the normal sweep WITHOUT its re-reads of the parked h tiles = the upper bound of
+                          // any scheme that keeps h_1 .. h_s resident through the sweep
+#define AVC_F_HLOAD(PH) fwd_abl_pair(t)
+#else
+#define AVC_F_HLOAD(PH) tile_load<false, h8>(tiles, (PH) + t)
+#endif
 #define AVC_F_NSTEP(OUT, PH)                                                                              \
-  AVC_PRE(return tile_load<false, h8>(tiles, (PH) + t);),                                                   \
+  AVC_PRE(return AVC_F_HLOAD(PH);),                                                                         \
   AVC_EPID(FragPair<h8>, _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                    \
             OUT[2 * t][j] = (_Float16)(acc[j] * sig_from_h((float)d.a0[j]));                                \
             OUT[2 * t + 1][j] = (_Float16)(acc[8 + j] * sig_from_h((float)d.a1[j])); }                      \

@@ -62,6 +62,9 @@ __device__ __forceinline__ StageT<G> stage_init(char* lds) {
 #ifndef AVC_DMA_TURNS
 #define AVC_DMA_TURNS 1
 #endif
+#ifndef AVC_DMA_ROT
+#define AVC_DMA_ROT 0
+#endif
 template <class ST>
 __device__ __forceinline__ void stage_issue(ST& st, const Next& nx, int buf, bool rotate = true) {
   if (!nx.ptr) return;
@@ -80,9 +83,23 @@ __device__ __forceinline__ void stage_issue(ST& st, const Next& nx, int buf, boo
     st.turn = nt >= nsub ? 0 : nt;
   }
 #endif
+#ifdef AVC_ABL_HALFDMA   // timing ablation only (garbage results): every second chunk -- is the cost proportional to the bytes?
+  stride *= 2;
+#endif
   for (int c = first; c < nx.chunks; c += stride) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + c * 1024 + st.lane * 16),
-                                     (__attribute__((address_space(3))) void*)(dst + c * 1024), 16, 0, 0);
+#if AVC_DMA_ROT          // experiment: workgroups walk the group's chunks from different starting points (same data, same LDS image)
+    int cs = c + (int)(blockIdx.x * 5u) % nx.chunks;
+    cs = cs >= nx.chunks ? cs - nx.chunks : cs;
+#else
+    const int cs = c;
+#endif
+#ifdef AVC_ABL_DMA_SAMESRC   // timing ablation only (garbage results): every chunk from the SAME 1 KiB of the blob -- L2 / fabric side or LDS / issue side?
+    const int src = 0;
+#else
+    const int src = cs;
+#endif
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + src * 1024 + st.lane * 16),
+                                     (__attribute__((address_space(3))) void*)(dst + cs * 1024), 16, 0, 0);
   }
 }
 

@@ -9,6 +9,7 @@ The modules own the parameters (weight-normed linears -> `linK.weight_g / weight
 differentiable torch expressions for API compatibility only.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -37,6 +38,27 @@ def dense_weight(lin):
         v = lin.weight_v
         return lin.weight_g * v / v.norm(dim=1, keepdim=True)
     return lin.weight
+
+
+_TORCH_PATH_SEEN = set()
+
+
+def _torch_module_path(module, what, x):
+    """The reference's module-level entry points (fields.py:72-107, 154-185) are kept for API compatibility as plain torch expressions
+    (rocBLAS through torch); the product's hot path never calls them -- NeuSRenderer.render and SDFNetwork.sdf go to the HIP engine.  A
+    caller that reaches them on the GPU is NOT on the accelerated path and is told so, once per entry point: AVC_TORCH_MODULE_PATH = warn
+    (default) | raise | quiet."""
+    if not x.is_cuda or what in _TORCH_PATH_SEEN:
+        return
+    mode = os.environ.get("AVC_TORCH_MODULE_PATH", "warn")
+    if mode == "raise":
+        raise RuntimeError("%s on a CUDA tensor is the torch API-compatibility expression, not the HIP engine (use NeuSRenderer.render / "
+                           "SDFNetwork.sdf); AVC_TORCH_MODULE_PATH=raise refuses it" % what)
+    _TORCH_PATH_SEEN.add(what)
+    if mode != "quiet":
+        import warnings
+        warnings.warn("%s on the GPU runs as plain torch ops (rocBLAS), NOT on the fused gfx950 kernels: the accelerated entry points are "
+                      "NeuSRenderer.render and SDFNetwork.sdf (AVC_TORCH_MODULE_PATH=raise | quiet)" % what, RuntimeWarning, stacklevel=3)
 
 
 class SDFNetwork(nn.Module):
@@ -82,6 +104,7 @@ class SDFNetwork(nn.Module):
 
     # -- API-compat torch expressions (not the hot path)
     def forward(self, inputs):
+        _torch_module_path(self, "SDFNetwork.forward / .gradient", inputs)
         inputs = embed(inputs * self.scale, self.multires)
         x = inputs
         for l, (W, b) in enumerate(self.dense()):
@@ -149,6 +172,7 @@ class RenderingNetwork(nn.Module):
         return out
 
     def forward(self, points, normals, view_dirs, feature_vectors):
+        _torch_module_path(self, "RenderingNetwork.forward", points)
         if self.mode == "idr":
             x = torch.cat([points, embed(view_dirs, self.multires_view), normals, feature_vectors], dim=-1)
         elif self.mode == "no_view_dir":

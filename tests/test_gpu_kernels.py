@@ -436,3 +436,54 @@ def test_fused_split_sums_and_unpacking_equal_the_torch_statement(small, R, S, s
         a, b = (g[lay.pbase[name]:lay.pbase[name] + n] for g in gs)
         rel = float((a - b).norm() / (a.norm() + 1e-30))
         assert rel < 2e-6, (name, rel)
+
+
+@gpu
+def test_sdf_kernel_with_64_points_per_wavefront_equals_the_default_kernel(tmp_path):
+    """mlp_sdf2_kernel (round 6, csrc/avc_mlp.h: two 32-point groups per wavefront, one wavefront per SIMD, activations in AGPRs;
+    AVC_SDF_POINTS_PER_WAVE=64, measured 12 % slower and therefore off: profiles/r06_ab_kernels.txt) computes every point with the same
+    instruction sequence as mlp_sdf_kernel -- the values must be EQUAL BIT FOR BIT, for both nets, ragged sizes, the scatter form and the
+    point form.  The default kernel is pinned against the oracle by test_sdf_and_point_forward.  (The launcher reads the switch once
+    per process: two child processes.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for ppw in ("32", "64"):
+        path = str(tmp_path / ("sdf_%s.pt" % ppw))
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "sdf_ppw_child.py"), path], env=dict(os.environ, AVC_SDF_POINTS_PER_WAVE=ppw),
+                           capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[ppw] = torch.load(path)
+    assert set(outs["32"]) == set(outs["64"]) and len(outs["32"]) == 24
+    for k, a in outs["32"].items():
+        assert torch.isfinite(a).all() and a.abs().max() > 0, k
+        assert torch.equal(a, outs["64"][k]), (k, (a - outs["64"][k]).abs().max().item())
+
+
+@gpu
+def test_module_level_torch_entry_points_announce_themselves_on_the_gpu(monkeypatch):
+    """fields.SDFNetwork.forward / .gradient and RenderingNetwork.forward (reference: fields.py:72-107, 154-185) are kept as plain torch
+    expressions for API compatibility; nothing on the product's hot path calls them.  A caller that does, on the GPU, is told once that it
+    is NOT on the HIP engine (no silent paths), can turn that into an error, and still gets the reference's values."""
+    import warnings
+    from avatarclip_amd import fields
+    rec, sd_sdf, sd_col, variance, sdf, col, var, ren, dev = _setup("neus_small.npz")
+    pts = (torch.rand(257, 3, generator=torch.Generator().manual_seed(3)) - 0.5).to(dev)
+    monkeypatch.setattr(fields, "_TORCH_PATH_SEEN", set())
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        y = sdf(pts)
+        g = sdf.gradient(pts.clone())
+        c = col(pts, g.squeeze(1), None, y[:, 1:])
+    said = [str(x.message) for x in w if issubclass(x.category, RuntimeWarning)]
+    assert len([m for m in said if "SDFNetwork.forward" in m]) == 1 and len([m for m in said if "RenderingNetwork.forward" in m]) == 1, said
+    ref = O.sdf_forward(sd_sdf, pts.cpu())
+    assert (y.detach().cpu() - ref).abs().max() < 1e-4 and c.shape == (257, 6)
+    assert (sdf.sdf(pts).cpu() - ref[:, :1]).abs().max() < 3e-3          # the accelerated entry point, same values
+    monkeypatch.setattr(fields, "_TORCH_PATH_SEEN", set())
+    monkeypatch.setenv("AVC_TORCH_MODULE_PATH", "raise")
+    with pytest.raises(RuntimeError, match="not the HIP engine"):
+        sdf(pts)
+

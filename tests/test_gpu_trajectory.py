@@ -15,7 +15,7 @@ weight vectors do NOT stay equal entry by entry -- after a few dozen steps they 
     yardstick for "the same avatar": two fp32 runs of one implementation drift apart as well), and >= 30 dB in any case;
   * the HIP renderer on ITS final weights against the oracle renderer on the same weights: the one-step forward gate (5e-3) still holds at
     the end of the run (weights that have left the initialisation: inv_s has grown, the surface has sharpened).
-Small nets (confs/examples_small), 32 x 32 full-frame rays, 16 + 16 samples per ray, lr warm-up off, 300 steps; two CPU legs of ~75 s each at 16 threads.
+Small nets (confs/examples_small), 32 x 32 full-frame rays, 16 + 16 samples per ray, lr warm-up off, 300 steps; the two CPU legs (~75 s each at 16 threads) run as spawned processes beside the HIP leg.
 """
 import numpy as np
 import pytest
@@ -30,6 +30,33 @@ WINDOWS = (50, 100, 200, 290)
 def _psnr(a, b):
     mse = float(((a.double() - b.double()) ** 2).mean())
     return 99.0 if mse == 0 else -10.0 * np.log10(mse)
+
+
+def _oracle_leg(p):
+    """One oracle leg in a process of its own (spawned: legs A and B run side by side, beside the HIP leg).  Everything heavy is rebuilt here
+    from seeds -- the stand-in CLIP weights, the procedural prior -- so that only the initial MLP weights and the recorded draws travel."""
+    import os
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))     # torch's default oversubscribes the many small ops of this path on a 256-core host
+    from oracle import iteration_oracle as IT
+    from oracle import neus_oracle as O
+    from avatarclip_amd.runner import clip_vit_random_state_dict, EllipsoidPrior
+    clip_sd = clip_vit_random_state_dict(0)
+    prior = EllipsoidPrior(device="cpu")
+    g = torch.Generator().manual_seed(31)
+    mv = lambda t: (t * (1 + p["perturb"] * torch.randn(t.shape, generator=g))).clone().requires_grad_()
+    st = IT.OracleState({n: mv(t) for n, t in p["sdf"].items()}, {n: mv(t) for n, t in p["color"].items()}, mv(p["variance"]), lr0=p["lr0"],
+                        alpha=p["alpha"], warm_up_end=p["warm_up_end"], end_iter=p["end_iter"])
+    R = p["rays"]
+    losses = []
+    for i, (eye, at, theta, phi, is_front) in enumerate(p["cams"]):
+        rs = np.random.RandomState(4321 + i)
+        light = O.sphere_coord(theta + rs.uniform(-np.pi / 4, np.pi / 4), phi + rs.uniform(-np.pi / 4, np.pi / 4))
+        amb = float(rs.uniform(0, 0.2))
+        dr = IT.Draws(eye=eye, at=at, theta=theta, phi=phi, is_front=is_front, prior_rgb=prior(eye, at),
+                      jitter=torch.rand(R, 1, generator=torch.Generator().manual_seed(100 + i)), choice_i=3, light_dir=light, ambience=amb)
+        losses.append(float(IT.train_clip_iteration(st, p["oconf"], dr, clip_sd, p["texts"], i)["loss"]))
+    return dict(losses=np.asarray(losses), sdf={k: t.detach() for k, t in st.sdf.items()}, color={k: t.detach() for k, t in st.color.items()},
+                variance=st.variance.detach(), lr=st.opt.param_groups[0]["lr"], iter_step=st.iter_step)
 
 
 @gpu
@@ -58,16 +85,19 @@ def test_300_iterations_track_the_independent_oracle():
     init = ({n: p.detach().cpu().clone() for n, p in a.sdf_network.named_parameters()}, {n: p.detach().cpu().clone() for n, p in a.color_network.named_parameters()},
             a.deviation_network.variance.detach().cpu().clone())
 
-    def oracle_state(rel_perturbation=0.0):
-        """the oracle's start: the product's initial weights, optionally moved by `rel_perturbation` (relative, seeded) -- leg B below"""
-        g = torch.Generator().manual_seed(31)
-        mv = lambda t: (t * (1 + rel_perturbation * torch.randn(t.shape, generator=g))).clone().requires_grad_()
-        return IT.OracleState({n: mv(t) for n, t in init[0].items()}, {n: mv(t) for n, t in init[1].items()}, mv(init[2]), lr0=a.learning_rate,
-                              alpha=a.learning_rate_alpha, warm_up_end=a.warm_up_end, end_iter=a.end_iter)
     texts = dict(prompt=a.encoded_text.cpu(), face_prompt=a.encoded_face_text.cpu(), back_prompt=a.encoded_back_text.cpu())
     oconf = _oracle_conf(a, a.dataset.H)
     R = res * res
     jitter = lambda i: torch.rand(R, 1, generator=torch.Generator().manual_seed(100 + i))
+    # ---------------- oracle legs (CPU), started first: two spawned processes beside the HIP leg.  A: from the product's initial weights.  B: the SAME
+    # oracle from weights moved by 1e-6 (relative): the optimisation is chaotic, so two fp32 runs of one implementation drift apart too, and B measures
+    # by how much -- the yardstick for "the HIP leg arrives at the same avatar" below.
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    payload = dict(sdf=init[0], color=init[1], variance=init[2], lr0=a.learning_rate, alpha=a.learning_rate_alpha, warm_up_end=a.warm_up_end,
+                   end_iter=a.end_iter, rays=R, cams=cams, oconf=oconf, texts=texts)
+    pool = ProcessPoolExecutor(2, mp_context=mp.get_context("spawn"))
+    legs = [pool.submit(_oracle_leg, dict(payload, perturb=pt)) for pt in (0.0, 1e-6)]
     # ---------------- HIP leg
     a_render = a.renderer.render
     jit = {}
@@ -81,30 +111,10 @@ def test_300_iterations_track_the_independent_oracle():
         a.update_learning_rate()
     loss_hip = torch.stack(loss_hip).cpu().double().numpy()
     assert np.isfinite(loss_hip).all()
-    # ---------------- oracle legs (CPU).  A: from the product's initial weights.  B: the SAME oracle from weights moved by 1e-6 (relative): the
-    # optimisation is chaotic, so two fp32 runs of one implementation drift apart too, and B measures by how much -- the yardstick for "the HIP leg
-    # arrives at the same avatar" below.  (Bounded thread count: on the GPU box's 256 host cores torch's default oversubscribes the many small ops
-    # of this path, 11 min for 300 iterations against ~75 s with 16 threads.)
-    import os
-    nthreads = torch.get_num_threads()
-    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
-
-    def oracle_leg(st):
-        losses = []
-        for i in range(N_ITERS):
-            eye, at, theta, phi, is_front = cams[i]
-            rs = np.random.RandomState(4321 + i)
-            light = O.sphere_coord(theta + rs.uniform(-np.pi / 4, np.pi / 4), phi + rs.uniform(-np.pi / 4, np.pi / 4))
-            amb = float(rs.uniform(0, 0.2))
-            dr = IT.Draws(eye=eye, at=at, theta=theta, phi=phi, is_front=is_front, prior_rgb=prior_of(i), jitter=jitter(i), choice_i=3,
-                          light_dir=light, ambience=amb)
-            losses.append(float(IT.train_clip_iteration(st, oconf, dr, clip_sd, texts, i)["loss"]))
-        return np.asarray(losses)
-    st, st_b = oracle_state(), oracle_state(1e-6)
-    loss_or = oracle_leg(st)
-    loss_or_b = oracle_leg(st_b)
-    torch.set_num_threads(nthreads)
-    assert abs(a.optimizer.param_groups[0]["lr"] - st.opt.param_groups[0]["lr"]) < 1e-12 and a.iter_step == st.iter_step == N_ITERS
+    leg_a, leg_b = [f.result(timeout=1500) for f in legs]
+    pool.shutdown()
+    loss_or, loss_or_b = leg_a["losses"], leg_b["losses"]
+    assert abs(a.optimizer.param_groups[0]["lr"] - leg_a["lr"]) < 1e-12 and a.iter_step == leg_a["iter_step"] == N_ITERS
     # ---------------- the curves
     print("iter   hip      oracle   (single iterations)")
     for i in (0, 1, 2, 5, 10, 20, 50, 100, 200, 299):
@@ -135,18 +145,16 @@ def test_300_iterations_track_the_independent_oracle():
     hip_s = {n: p.detach().cpu() for n, p in a.sdf_network.named_parameters()}
     hip_c = {n: p.detach().cpu() for n, p in a.color_network.named_parameters()}
     hip_v = a.deviation_network.variance.detach().cpu()
-    r_or = O.render({k: t.detach() for k, t in st.sdf.items()}, {k: t.detach() for k, t in st.color.items()}, st.variance.detach(), ro, rd, near, far,
-                    spp // 2, spp // 2, 4, jt, bg, 1.0)
+    r_or = O.render(leg_a["sdf"], leg_a["color"], leg_a["variance"], ro, rd, near, far, spp // 2, spp // 2, 4, jt, bg, 1.0)
     r_hw = O.render(hip_s, hip_c, hip_v, ro, rd, near, far, spp // 2, spp // 2, 4, jt, bg, 1.0)
-    r_ob = O.render({k: t.detach() for k, t in st_b.sdf.items()}, {k: t.detach() for k, t in st_b.color.items()}, st_b.variance.detach(), ro, rd, near, far,
-                    spp // 2, spp // 2, 4, jt, bg, 1.0)
+    r_ob = O.render(leg_b["sdf"], leg_b["color"], leg_b["variance"], ro, rd, near, far, spp // 2, spp // 2, 4, jt, bg, 1.0)
     p_col = _psnr(r_hw["extra_color_fine"].detach(), r_or["extra_color_fine"].detach())
     p_sil = _psnr(r_hw["weight_sum"].detach(), r_or["weight_sum"].detach())
     q_col = _psnr(r_ob["extra_color_fine"].detach(), r_or["extra_color_fine"].detach())
     q_sil = _psnr(r_ob["weight_sum"].detach(), r_or["weight_sum"].detach())
     print("held-out view under ONE renderer (the oracle's), final weights:  HIP vs oracle A: colour %.2f dB, silhouette %.2f dB   |   oracle B vs oracle A (the "
           "optimisation's own chaos, start moved by 1e-6): colour %.2f dB, silhouette %.2f dB;   inv_s %.3f / %.3f / %.3f"
-          % (p_col, p_sil, q_col, q_sil, float(torch.exp(hip_v * 10)), float(torch.exp(st.variance.detach() * 10)), float(torch.exp(st_b.variance.detach() * 10))))
+          % (p_col, p_sil, q_col, q_sil, float(torch.exp(hip_v * 10)), float(torch.exp(leg_a["variance"] * 10)), float(torch.exp(leg_b["variance"] * 10))))
     # the HIP leg is as close to the oracle as the oracle is to itself (3 dB of slack), and never worse than 30 dB; two runs measured 38.9 / 36.3 and
     # 36.5 / 33.9 dB against oracle legs that differed only in their thread count (profiles/r06_trajectory.md)
     assert p_col >= min(35.0, q_col - 3.0) and p_sil >= min(35.0, q_sil - 3.0) and min(p_col, p_sil) >= 30.0

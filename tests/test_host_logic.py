@@ -117,6 +117,36 @@ def test_fields_state_dict_compat_and_torch_forward():
     assert flat.numel() == PK.layout_for(PK.SMALL).nparam
 
 
+def test_runner_loads_the_reference_s_own_conf_and_shipped_checkpoint(tmp_path, monkeypatch):
+    """the reference's shipped `pretrained_models/zero_beta_stand_pose_small.pth` through the product's OWN loading path --
+    Runner.__init__ on the reference's confs/examples_small/example.conf UNMODIFIED (its relative `train.pretrain`, main.py:153-155 -> Runner.load_pretrain,
+    main.py:611-618 incl. the non-strict colour load that leaves `extra_lin` at its seeded init) -- and not only via a golden state dict.  The loaded
+    weights must equal the ones oracle/gen_golden.py read with the reference's modules (tests/golden/neus_small.npz).  Needs the reference tree (build
+    container); the GPU box never holds it."""
+    from oracle import ref_loader
+    if not ref_loader.reference_available():
+        pytest.skip("no reference tree on this machine")
+    from avatarclip_amd.conf import ConfigFactory
+    from avatarclip_amd.runner import Runner
+    ag = ref_loader.REF_AG
+    conf_path = os.path.join(ag, "confs", "examples_small", "example.conf")
+    conf = ConfigFactory.parse_string(open(conf_path).read())
+    assert conf.get_string("train.pretrain") == "./pretrained_models/zero_beta_stand_pose_small.pth"
+    conf.put("general.base_exp_dir", str(tmp_path / "exp"))          # (the only edit: the reference tree is read-only)
+    monkeypatch.chdir(ag)                                            # the conf's paths are relative to AppearanceGen/, as `python main.py` runs there
+    r = Runner(conf_path, mode="train_clip", conf=conf, device=torch.device("cpu"), allow_standins=True)
+    rec, sd_sdf, sd_col, variance = load_case("neus_small.npz")
+    for k, v in sd_sdf.items():
+        assert torch.equal(r.sdf_network.state_dict()[k], v), k
+    assert torch.equal(r.deviation_network.variance.detach(), variance)
+    ck = r._torch_load(os.path.join(ag, "pretrained_models", "zero_beta_stand_pose_small.pth"))     # (the tensors-only unpickler + numpy scalars: the file's optimizer state holds one)
+    loaded = r.color_network.state_dict()
+    for k, v in ck["color_network_fine"].items():                    # every tensor the checkpoint HAS is loaded ...
+        assert torch.equal(loaded[k], v), k
+    assert {k for k in loaded if k not in ck["color_network_fine"]} == {"extra_lin.bias", "extra_lin.weight_g", "extra_lin.weight_v"}   # ... main.py:617
+    assert r.iter_step == 0 and set(ck.keys()) >= {"sdf_network_fine", "variance_network_fine", "color_network_fine"}
+
+
 def test_c_abi_exports_every_declared_symbol():
     from avatarclip_amd import build
     path = build.build()

@@ -255,26 +255,33 @@ def test_dense_gradient_under_a_coherent_loss_at_16k_and_262k_points(monkeypatch
 
 
 @gpu
-def test_fullsize_gradient_linearity_and_chunk_invariance():
+@pytest.mark.parametrize("spp", [64, 128])
+def test_fullsize_gradient_linearity_and_chunk_invariance(spp):
+    """spp = 128: BASELINE config 3's per-GPU share at FULL size through the training path -- 174 GiB of forward-type panels in one launch, the
+    gradient-type slab sized from what is left (several slabs), block offsets far beyond 2^32 bytes in both regions (round 6)."""
+    import gc
     from avatarclip_amd.engine import Engine
+    gc.collect()
+    torch.cuda.empty_cache()
     dev = torch.device("cuda")
-    sdf, col, var, ren = _full_renderer(dev)
+    sdf, col, var, ren = _full_renderer(dev, spp // 2, spp // 2)
     ro, rd, near, far = _view(512, dev)
     eng = ren.engine
     pk = eng.pack(ren.flat_params())
     with torch.no_grad():
         z = ren.sample_z(pk, ro, rd, near, far, 1.0)
     R, S = z.shape
-    assert (R, S) == (512 * 512, 64)
+    assert (R, S) == (512 * 512, spp)
     g = torch.Generator(device=dev).manual_seed(5)
     d_sdf = torch.randn(R, S, device=dev, generator=g) * 1e-3
     d_n = torch.randn(R, S, 3, device=dev, generator=g) * 1e-3
     d_rgb = torch.randn(R, S, 6, device=dev, generator=g) * 1e-3
     # the training forward leaves the forward-type operand panels of the whole view (87 GiB) in the engine's F region; the first
     # backward uses them, the second one finds them still there (the backward only writes the per-slab G region)
-    _, _, rgb = eng.points_fwd_train(pk, ro, rd, z, 2.0 / 32)
-    g1 = eng.points_bwd(pk, ro, rd, z, 2.0 / 32, d_sdf, d_n, d_rgb, rgb, panels_valid=True)
-    g2 = eng.points_bwd(pk, ro, rd, z, 2.0 / 32, 2 * d_sdf, 2 * d_n, 2 * d_rgb, rgb, panels_valid=True)
+    assert eng.plan(R, S)[0] >= R, "one forward launch for the whole view on a 288 GB device"
+    _, _, rgb = eng.points_fwd_train(pk, ro, rd, z, 2.0 / (spp // 2))
+    g1 = eng.points_bwd(pk, ro, rd, z, 2.0 / (spp // 2), d_sdf, d_n, d_rgb, rgb, panels_valid=True)
+    g2 = eng.points_bwd(pk, ro, rd, z, 2.0 / (spp // 2), 2 * d_sdf, 2 * d_n, 2 * d_rgb, rgb, panels_valid=True)
     torch.cuda.synchronize()
     assert torch.isfinite(g1).all() and g1.abs().max() > 0
     # every kernel is exactly linear under power-of-two scaling; the final scatter of the (i)/(ii) products into the dense
@@ -287,7 +294,7 @@ def test_fullsize_gradient_linearity_and_chunk_invariance():
         Engine.PANEL_BYTES_BUDGET = 3 << 30      # many more, smaller launches: the backward re-runs the training forward per chunk
         chunk, slab = eng.plan(R, S)
         assert chunk < R and slab <= chunk and chunk % 32 == 0, (chunk, slab)   # the budget applies although larger buffers are at hand
-        g3 = eng.points_bwd(pk, ro, rd, z, 2.0 / 32, d_sdf, d_n, d_rgb, rgb)
+        g3 = eng.points_bwd(pk, ro, rd, z, 2.0 / (spp // 2), d_sdf, d_n, d_rgb, rgb)
     finally:
         Engine.PANEL_BYTES_BUDGET = old
     torch.cuda.synchronize()

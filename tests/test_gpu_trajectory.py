@@ -36,6 +36,16 @@ def _oracle_leg(p):
     """One oracle leg in a process of its own (spawned: legs A and B run side by side, beside the HIP leg).  Everything heavy is rebuilt here
     from seeds -- the stand-in CLIP weights, the procedural prior -- so that only the initial MLP weights and the recorded draws travel."""
     import os
+    import time
+    t_start = time.time()
+    try:        # the two legs on DISJOINT cores (both would otherwise start their 16 threads on the same ones and halve each other)
+        cores = sorted(os.sched_getaffinity(0))
+        if len(cores) >= 64:
+            mine = cores[16 + 24 * p["slot"]: 16 + 24 * p["slot"] + 16]     # (the first cores are left to the parent's launch thread; measured on the
+                                                                             # 2 x 64-core box: 145 s per leg like this, 166 s on different sockets, 178 s unpinned, ~80 s alone)
+            os.sched_setaffinity(0, mine)
+    except (AttributeError, OSError):
+        pass
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))     # torch's default oversubscribes the many small ops of this path on a 256-core host
     from oracle import iteration_oracle as IT
     from oracle import neus_oracle as O
@@ -55,7 +65,8 @@ def _oracle_leg(p):
         dr = IT.Draws(eye=eye, at=at, theta=theta, phi=phi, is_front=is_front, prior_rgb=prior(eye, at),
                       jitter=torch.rand(R, 1, generator=torch.Generator().manual_seed(100 + i)), choice_i=3, light_dir=light, ambience=amb)
         losses.append(float(IT.train_clip_iteration(st, p["oconf"], dr, clip_sd, p["texts"], i)["loss"]))
-    return dict(losses=np.asarray(losses), sdf={k: t.detach() for k, t in st.sdf.items()}, color={k: t.detach() for k, t in st.color.items()},
+    print("oracle leg %d: %.1f s" % (p["slot"], time.time() - t_start), flush=True)
+    return dict(losses=np.asarray(losses), seconds=time.time() - t_start, sdf={k: t.detach() for k, t in st.sdf.items()}, color={k: t.detach() for k, t in st.color.items()},
                 variance=st.variance.detach(), lr=st.opt.param_groups[0]["lr"], iter_step=st.iter_step)
 
 
@@ -97,7 +108,7 @@ def test_300_iterations_track_the_independent_oracle():
     payload = dict(sdf=init[0], color=init[1], variance=init[2], lr0=a.learning_rate, alpha=a.learning_rate_alpha, warm_up_end=a.warm_up_end,
                    end_iter=a.end_iter, rays=R, cams=cams, oconf=oconf, texts=texts)
     pool = ProcessPoolExecutor(2, mp_context=mp.get_context("spawn"))
-    legs = [pool.submit(_oracle_leg, dict(payload, perturb=pt)) for pt in (0.0, 1e-6)]
+    legs = [pool.submit(_oracle_leg, dict(payload, perturb=pt, slot=k)) for k, pt in enumerate((0.0, 1e-6))]
     # ---------------- HIP leg
     a_render = a.renderer.render
     jit = {}
@@ -114,6 +125,7 @@ def test_300_iterations_track_the_independent_oracle():
     leg_a, leg_b = [f.result(timeout=1500) for f in legs]
     pool.shutdown()
     loss_or, loss_or_b = leg_a["losses"], leg_b["losses"]
+    print("oracle legs: %.1f s / %.1f s (side by side)" % (leg_a["seconds"], leg_b["seconds"]))
     assert abs(a.optimizer.param_groups[0]["lr"] - leg_a["lr"]) < 1e-12 and a.iter_step == leg_a["iter_step"] == N_ITERS
     # ---------------- the curves
     print("iter   hip      oracle   (single iterations)")

@@ -166,12 +166,12 @@ _NO_RENDERER_GRADIENT = ("%s optimises the CLIP score with respect to the pose T
 
 
 class PoseOptimizer:
-    def __init__(self, ctx=None, **kw):
+    def __init__(self, ctx=None, **conf):
         raise NotImplementedError(_NO_RENDERER_GRADIENT % "PoseOptimizer (pose_generation.py:102-135)")
 
 
 class VPoserOptimizer:
-    def __init__(self, ctx=None, **kw):
+    def __init__(self, ctx=None, **conf):
         raise NotImplementedError(_NO_RENDERER_GRADIENT % "VPoserOptimizer (pose_generation.py:138-173)")
 
 
@@ -182,7 +182,7 @@ class VPoserCodebook:
     codes, `codebook_embedding` [N,512] (the reference's data/codebook.pth: pass its path as `codebook_path`, or the two tensors)."""
 
     def __init__(self, ctx, codebook=None, codebook_embedding=None, codebook_path="data/codebook.pth", topk=5, pre_topk=40, filter_threshold=0.07,
-                 name="VPoserCodebook", **unused):
+                 name="VPoserCodebook", smpl_path=None, vposer_path=None):       # (smpl_path / vposer_path: the reference's base-class keys; the assets are in `ctx`)
         self.ctx, self.name, self.topk, self.pre_topk, self.filter_threshold = ctx, name, int(topk), int(pre_topk), float(filter_threshold)
         if codebook is None:
             data = torch.load(codebook_path, map_location="cpu", weights_only=True)
@@ -215,7 +215,7 @@ class VPoserRealNVP(nn.Module):
     (`s.{i}.{0,2,4}`, `t.{i}.{0,2,4}`, buffer `mask`), so data/pose_realnvp.pth's `state_dict` loads as it is."""
 
     def __init__(self, ctx, dim=32, hdim=256, num_block=8, num_sample=10, num_batch=50, ckpt_path=None, state_dict=None, topk=5, name="VPoserRealNVP",
-                 **unused):
+                 smpl_path=None, vposer_path=None):
         super().__init__()
         self.ctx, self.name, self.topk = ctx, name, int(topk)
         self.dim, self.num_block, self.num_sample, self.num_batch = dim, num_block, num_sample, num_batch
@@ -282,7 +282,7 @@ class MotionInterpolation:
     """motion_generation.py:100-137: the candidate poses encoded by VPoser, placed at the anchor frames, the latent code walked linearly between
     consecutive anchors, every frame decoded -> [num_frame, 69]"""
 
-    def __init__(self, ctx, num_frame=60, anchor_position=(0, 14, 29, 44, 59), name="MotionInterpolation", **unused):
+    def __init__(self, ctx, num_frame=60, anchor_position=(0, 14, 29, 44, 59), name="MotionInterpolation", smpl_path=None, vposer_path=None):
         self.ctx, self.name, self.num_frame, self.anchor_position = ctx, name, int(num_frame), tuple(int(a) for a in anchor_position)
         if self.anchor_position[0] != 0 or self.anchor_position[-1] != self.num_frame - 1:
             raise ValueError("the anchors start at frame 0 and end at the last frame")
@@ -363,7 +363,8 @@ class MotionOptimizer(nn.Module):
     must be 0 (see the module docstring).  Decoder / encoder parameter names are the reference's: data/motion_vae.pth's `state_dict` loads as it is."""
 
     def __init__(self, ctx, num_frame=60, latent_dim=256, num_layers=4, num_heads=4, ckpt_path=None, state_dict=None, optim_name="Adam", optim_cfg=None,
-                 num_iteration=5000, recon_coef=(1, 0.8, 0.6, 0.4, 0.2), clip_coef=0.001, delta_coef=0.01, clip_num_part=30, name="MotionOptimizer", **unused):
+                 num_iteration=5000, recon_coef=(1, 0.8, 0.6, 0.4, 0.2), clip_coef=0.001, delta_coef=0.01, clip_num_part=30, name="MotionOptimizer",
+                 smpl_path=None, vposer_path=None):
         super().__init__()
         if float(clip_coef) > 0:
             raise NotImplementedError(_NO_RENDERER_GRADIENT % ("MotionOptimizer with clip_coef = %g (motion_generation.py:333-345)" % clip_coef))
@@ -377,6 +378,8 @@ class MotionOptimizer(nn.Module):
             self.load_state_dict(state_dict, strict=False)
         self.optim_name, self.optim_cfg, self.num_iteration = optim_name, dict(optim_cfg or {"lr": 0.01}), int(num_iteration)
         self.recon_coef, self.delta_coef = tuple(float(c) for c in recon_coef), float(delta_coef)
+        if self.num_iteration < 1:
+            raise ValueError("num_iteration must be at least 1")
         self.to(ctx.device).eval()
 
     def decode(self, latent_code):

@@ -82,6 +82,9 @@ def test_latent_interpolation_matches_the_reference_method():
     assert torch.equal(motion[:, 63:], torch.zeros(60, 6))
     with pytest.raises(ValueError):
         A.MotionInterpolation(_ctx(), num_frame=60, anchor_position=(0, 10, 58))
+    with pytest.raises(TypeError):          # a mistyped conf key is an error, as with the reference's explicit signatures
+        A.build_motion_generator({"type": "MotionInterpolation", "anchor_positon": (0, 59)}, _ctx())
+    assert A.build_motion_generator({"type": "MotionInterpolation", "smpl_path": "../smpl_models"}, _ctx()).num_frame == 60
 
 
 def test_motion_vae_and_latent_optimisation_match_the_reference_class():

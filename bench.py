@@ -217,17 +217,19 @@ def load_pmc():
     return {}, None
 
 
-def build_runner(res, spp, small, dev):
+def build_runner(res, spp, small, dev, overrides=None, mesh_prior=True):
     from avatarclip_amd.runner import Runner
     # identical initial weights on every rank (train.seed = 0 in the conf + broadcast); the Runner then re-seeds the DATA RNGs
     # per rank (a different camera view, jitter and light per rank: view-sharded DP, Runner.seed_data_rngs)
     conf = make_conf(res, spp, small)
+    for k, v in (overrides or {}).items():
+        conf.put(k, v)
     runner = Runner(None, mode="train_clip", conf=conf, device=dev)
     runner.init_clip()
     # the silhouette / colour prior: the SMPL template mesh (reference data/zero_beta_smpl.obj, packed in the test fixture) through
     # the HIP rasteriser with neural_renderer's conventions -- the same per-iteration work as main.py:360
     mesh_npz = os.path.join(ROOT, "tests", "golden", "smpl_views.npz")
-    if os.path.exists(mesh_npz):
+    if mesh_prior and os.path.exists(mesh_npz):
         from avatarclip_amd.smpl_prior import MeshPrior
         z = np.load(mesh_npz)
         runner.init_smpl(MeshPrior(z["mesh_v"], z["mesh_f"], device=dev))
@@ -442,6 +444,27 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             torch.cuda.reset_peak_memory_stats(dev)
+        # the reference's DEFAULT sampling mode (confs/examples/*.conf: use_silhouettes, max_ray_num = 7000, background augmentation): a ragged,
+        # data-dependent ray set per iteration -- a reported extra, not the metric (profiles/r06_silhouette_mode.txt says where its time goes)
+        try:
+            # (the procedural ellipsoid prior, as scripts/silhouette_time.py: the T-pose template mesh of the headline run leaves the face
+            # cameras of main.py:349-352 looking past it -- an empty prior, where the reference fails as well, dataset.py:253-254)
+            r3 = build_runner(512, 64, False, dev, {"train.use_silhouettes": True, "train.max_ray_num": 7000, "train.use_bg_aug": True}, mesh_prior=False)
+            for i in range(8):
+                r3.train_clip_iteration(i); r3.update_learning_rate()
+            torch.cuda.synchronize()
+            t0, rays, n3 = time.perf_counter(), 0, 30
+            for i in range(8, 8 + n3):
+                r3.train_clip_iteration(i); r3.update_learning_rate(); rays += int(r3.last_stats["rays"])
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t0
+            extras["default_silhouette_mode_7000rays_64spp"] = {"value": rays / dt3, "unit": "rays/s", "ms_per_step": 1e3 * dt3 / n3, "iters_per_sec": n3 / dt3,
+                                                                "steps": n3, "warmup": 8, "rays_per_step": rays / n3}
+            del r3
+        except Exception as e:
+            extras["default_silhouette_mode_7000rays_64spp"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        gc.collect()
+        torch.cuda.empty_cache()
         out["extra_configs"] = extras
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
